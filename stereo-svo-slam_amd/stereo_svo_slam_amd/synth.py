@@ -1,0 +1,194 @@
+"""Seeded synthetic stereo sequences (no dataset ships with the reference:
+the Blender .mkv files are stripped and EuRoC is not redistributable).
+
+A closed room of textured planes plus a few free-standing panels is ray-cast
+into a rectified pinhole stereo pair with the reference's conventions:
+
+* pose = camera in world, point_cam = R(-r) (P - t)   (src/lib/transform_keypoints.cpp:32-45)
+* the library's `left` image is the camera at the pose; `right` is displaced
+  by -baseline/fx along the camera x axis, so a point at column u in `left`
+  appears at u + baseline/z in `right` (the disparity search of
+  src/lib/depth_filter.cpp:293-302 runs toward +x).
+
+Pure torch, runs on CPU (tests) and on the GPU (bench); used for inputs only.
+"""
+import math
+
+import numpy as np
+import torch
+
+# camera presets: BASELINE.json configs mapped onto the reference's YAMLs
+# (src/app/EuRoC.yaml:35-43, src/app/Blender.yaml:42-59, src/app/Econ.yaml:9-48)
+CONFIGS = {
+    # C2: EuRoC MH_02 class, 752x480, 6/2 levels ("4-level"), ~130-200 patches
+    "euroc": dict(width=752, height=480, fx=435.2046959714599, fy=435.2046959714599,
+                  cx=367.4517211914062, cy=252.2008514404297, baseline=47.90639384423901,
+                  k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0, grid_width=54, grid_height=48,
+                  search_x=60, search_y=6, window_size_pose_estimator=4,
+                  window_size_opt_flow=31, window_size_depth_calculator=31,
+                  max_pyramid_levels=6, min_pyramid_level_pose_estimation=2),
+    # C1: Blender classroom, 752x480, 5/2 levels ("3-level")
+    "blender": dict(width=752, height=480, fx=470.0, fy=470.0, cx=376.0, cy=240.0, baseline=28.2,
+                    k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0, grid_width=75, grid_height=48,
+                    search_x=50, search_y=6, window_size_pose_estimator=4,
+                    window_size_opt_flow=31, window_size_depth_calculator=31,
+                    max_pyramid_levels=5, min_pyramid_level_pose_estimation=2),
+    # C3: synthetic 1920x1080, 2000 patches, 7/2 levels ("5-level")
+    "hd": dict(width=1920, height=1080, fx=1200.0, fy=1200.0, cx=960.0, cy=540.0, baseline=72.0,
+               k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0, grid_width=43, grid_height=24,
+               search_x=60, search_y=6, window_size_pose_estimator=4,
+               window_size_opt_flow=31, window_size_depth_calculator=31,
+               max_pyramid_levels=7, min_pyramid_level_pose_estimation=2),
+    # C5: Econ Tara, distortion != 0 (applied in projection only), windows 35
+    "econ": dict(width=752, height=480, fx=743.8041254687444, fy=743.8041254687444,
+                 cx=365.86266803741455, cy=238.70182609558105, baseline=45.1932,
+                 k1=0.12598132, k2=-0.22447148, k3=0.09229389, p1=0.00074527, p2=0.00802387,
+                 grid_width=40, grid_height=50, search_x=60, search_y=6,
+                 window_size_pose_estimator=4, window_size_opt_flow=35,
+                 window_size_depth_calculator=35, max_pyramid_levels=5,
+                 min_pyramid_level_pose_estimation=2),
+    # small case for fast CPU tests
+    "tiny": dict(width=320, height=240, fx=200.0, fy=200.0, cx=160.0, cy=120.0, baseline=20.0,
+                 k1=0.0, k2=0.0, k3=0.0, p1=0.0, p2=0.0, grid_width=40, grid_height=40,
+                 search_x=30, search_y=4, window_size_pose_estimator=4,
+                 window_size_opt_flow=21, window_size_depth_calculator=21,
+                 max_pyramid_levels=4, min_pyramid_level_pose_estimation=1),
+}
+
+CAMERA_FIELDS = ("baseline", "fx", "fy", "cx", "cy", "k1", "k2", "k3", "p1", "p2",
+                 "grid_height", "grid_width", "search_x", "search_y",
+                 "window_size_pose_estimator", "window_size_opt_flow",
+                 "window_size_depth_calculator", "max_pyramid_levels",
+                 "min_pyramid_level_pose_estimation")
+
+
+def rodrigues(r):
+    """float64 3x3 rotation of the axis-angle vector r (numpy)."""
+    r = np.asarray(r, np.float64)
+    th = np.linalg.norm(r)
+    if th < 1e-15:
+        return np.eye(3)
+    k = r / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return math.cos(th) * np.eye(3) + (1 - math.cos(th)) * np.outer(k, k) + math.sin(th) * K
+
+
+def trajectory(n_frames, seed=0, scale=1.0):
+    """Smooth 6-DoF camera path, <= ~2 cm and <= ~0.2 deg per frame; frame 0 at the origin."""
+    rng = np.random.RandomState(1000 + seed)
+    ph = rng.uniform(0, 2 * math.pi, 6)
+    k = np.arange(n_frames, dtype=np.float64)[:, None]
+    amp = np.array([0.25, 0.10, 0.20, 0.03, 0.05, 0.02]) * scale
+    om = np.array([0.05, 0.08, 0.04, 0.06, 0.045, 0.07])
+    p = amp * (np.sin(om * k + ph) - np.sin(ph))
+    return p.astype(np.float32)
+
+
+def _texture(rng, size=1024):
+    t = np.full((size, size), 128.0, np.float32)
+    for s, a in ((128, 28.0), (64, 26.0), (32, 24.0), (16, 20.0), (8, 14.0), (4, 8.0)):
+        t += np.kron(rng.uniform(-a, a, (size // s, size // s)).astype(np.float32),
+                     np.ones((s, s), np.float32))
+    t = 0.25 * (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(np.roll(t, 1, 0), 1, 1))
+    return np.clip(t, 16, 240)
+
+
+class Scene:
+    """Planes: (p0, u, v, half_u, half_v) with u,v orthonormal in-plane axes;
+    half extents <= 0 mean unbounded."""
+
+    def __init__(self, seed=0, device="cpu", texels_per_meter=170.0):
+        rng = np.random.RandomState(20241004 + seed)
+        self.device = torch.device(device)
+        self.tpm = texels_per_meter
+        ex, ey, ez = np.eye(3)
+        planes = [
+            ((0, 0, 6.5), ex, ey, 0, 0),        # back wall
+            ((0, 1.6, 0), ex, ez, 0, 0),        # floor (y is down)
+            ((0, -1.7, 0), ex, ez, 0, 0),       # ceiling
+            ((-3.2, 0, 0), ez, ey, 0, 0),       # left wall
+            ((3.4, 0, 0), ez, ey, 0, 0),        # right wall
+            ((0, 0, -3.0), ex, ey, 0, 0),       # wall behind the camera
+        ]
+        for _ in range(5):                       # free-standing panels
+            c = (rng.uniform(-2.0, 2.0), rng.uniform(-0.8, 0.9), rng.uniform(2.2, 4.8))
+            yaw = rng.uniform(-0.5, 0.5)
+            u = np.array([math.cos(yaw), 0, math.sin(yaw)])
+            planes.append((c, u, ey, rng.uniform(0.35, 0.8), rng.uniform(0.3, 0.7)))
+        self.planes = []
+        for p0, u, v, hu, hv in planes:
+            tex = torch.from_numpy(_texture(rng)).to(self.device)
+            self.planes.append(dict(
+                p0=torch.tensor(p0, dtype=torch.float64, device=self.device),
+                u=torch.tensor(np.asarray(u, np.float64), device=self.device),
+                v=torch.tensor(np.asarray(v, np.float64), device=self.device),
+                hu=float(hu), hv=float(hv), tex=tex,
+                off=(float(rng.uniform(0, 1024)), float(rng.uniform(0, 1024)))))
+
+    def render(self, cfg, pose, right=False, noise_sigma=1.0, noise_seed=None):
+        """uint8 (height, width) image of the camera at `pose` (6 floats)."""
+        dev = self.device
+        w, h = cfg["width"], cfg["height"]
+        pose = np.asarray(pose, np.float64)
+        R = torch.tensor(rodrigues(pose[3:6]), dtype=torch.float64, device=dev)
+        o = torch.tensor(pose[0:3], dtype=torch.float64, device=dev)
+        if right:
+            b = cfg["baseline"] / cfg["fx"]
+            o = o + R @ torch.tensor([-b, 0.0, 0.0], dtype=torch.float64, device=dev)
+        xs = (torch.arange(w, dtype=torch.float64, device=dev) - cfg["cx"]) / cfg["fx"]
+        ys = (torch.arange(h, dtype=torch.float64, device=dev) - cfg["cy"]) / cfg["fy"]
+        dc = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w),
+                          torch.ones(h, w, dtype=torch.float64, device=dev)], -1)
+        d = dc @ R.T                                            # world ray directions
+        best_s = torch.full((h, w), float("inf"), dtype=torch.float64, device=dev)
+        img = torch.zeros(h, w, dtype=torch.float32, device=dev)
+        for pl in self.planes:
+            n = torch.linalg.cross(pl["u"], pl["v"])
+            dn = d @ n
+            s = ((pl["p0"] - o) @ n) / dn
+            q = o + s[..., None] * d - pl["p0"]
+            tu, tv = q @ pl["u"], q @ pl["v"]
+            ok = (s > 1e-3) & (s < best_s) & torch.isfinite(s)
+            if pl["hu"] > 0:
+                ok &= (tu.abs() < pl["hu"]) & (tv.abs() < pl["hv"])
+            fu = tu * self.tpm + pl["off"][0]
+            fv = tv * self.tpm + pl["off"][1]
+            iu, iv = torch.floor(fu), torch.floor(fv)
+            au, av = (fu - iu).float(), (fv - iv).float()
+            size = pl["tex"].shape[0]
+            iu0 = torch.remainder(iu, size).long()
+            iv0 = torch.remainder(iv, size).long()
+            iu1 = torch.remainder(iu0 + 1, size)
+            iv1 = torch.remainder(iv0 + 1, size)
+            iu0 = torch.where(ok, iu0, torch.zeros_like(iu0))
+            iv0 = torch.where(ok, iv0, torch.zeros_like(iv0))
+            iu1 = torch.where(ok, iu1, torch.zeros_like(iu1))
+            iv1 = torch.where(ok, iv1, torch.zeros_like(iv1))
+            t = pl["tex"]
+            val = (t[iv0, iu0] * (1 - au) * (1 - av) + t[iv0, iu1] * au * (1 - av) +
+                   t[iv1, iu0] * (1 - au) * av + t[iv1, iu1] * au * av)
+            img = torch.where(ok, val, img)
+            best_s = torch.where(ok, s, best_s)
+        if noise_sigma > 0:
+            if noise_seed is None:
+                img = img + noise_sigma * torch.randn(h, w, device=dev)
+            else:
+                g = np.random.RandomState(noise_seed).standard_normal((h, w)).astype(np.float32)
+                img = img + noise_sigma * torch.from_numpy(g).to(dev)
+        return img.round().clamp(0, 255).to(torch.uint8)
+
+
+def make_sequence(config="euroc", n_frames=10, seed=0, device="cpu", noise_sigma=1.0,
+                  motion_scale=1.0):
+    """Returns (cfg, lefts, rights, poses, timestamps); lefts/rights are lists
+    of uint8 torch tensors on `device`; poses float32 [n,6] ground truth."""
+    cfg = dict(CONFIGS[config])
+    scene = Scene(seed, device)
+    poses = trajectory(n_frames, seed, motion_scale)
+    lefts, rights = [], []
+    for k in range(n_frames):
+        ns = None if noise_sigma <= 0 else 7919 * (seed + 1) + 2 * k
+        lefts.append(scene.render(cfg, poses[k], False, noise_sigma, ns))
+        rights.append(scene.render(cfg, poses[k], True, noise_sigma, None if ns is None else ns + 1))
+    ts = np.arange(n_frames, dtype=np.float32) / 20.0
+    return cfg, lefts, rights, poses, ts
