@@ -1,0 +1,256 @@
+// klt.hip — row B2 of SURVEY §8a: OpticalFlow::calculate_optical_flow
+// (src/lib/optical_flow.cpp:14-56) = cv::calcOpticalFlowPyrLK with a (w,w)
+// window, maxLevel 2, 30 iterations / eps 0.01, OPTFLOW_USE_INITIAL_FLOW,
+// tracking every keypoint from the Gaussian pyramid of its ORIGIN KEYFRAME
+// into the current frame (PoseRefiner::refine_pose, src/lib/pose_refinement.cpp:72-118).
+//
+// One wavefront per keypoint, all pyramid levels and iterations inside the
+// kernel. Per level the (w+3)^2 neighbourhood of the reference point is staged
+// in LDS with BORDER_REFLECT_101 addressing, the Scharr derivatives of
+// OpenCV's pyramid are computed from that tile (zero outside the image, as
+// the constant border of cv::buildOpticalFlowPyramid), and the fixed-point
+// template (14-bit weights, 5 fractional bits) stays in LDS for the
+// iterations. All window sums are exact integers reduced across the wave,
+// so the result does not depend on the reduction order.
+#include "svo_kernels.hpp"
+
+namespace svo {
+
+constexpr int KLT_MAX_WIN = 35;
+constexpr int KLT_RW = KLT_MAX_WIN + 3;
+constexpr int KLT_DW = KLT_MAX_WIN + 1;
+
+#define SVO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+__device__ inline int cv_round(float v) { return (int)rintf(v); }
+__device__ inline int cv_floor(float v) { return (int)floorf(v); }
+
+__global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict__ args) {
+    const KltArgs& a = args[blockIdx.y];
+    const int n = *a.n_ptr;
+    const int kp = blockIdx.x;
+    if (kp >= n) return;
+    const int lane = threadIdx.x;
+    const int win = a.win;
+    const int RW = win + 3, DW = win + 1;
+
+    __shared__ uint8_t s_I[KLT_RW * KLT_RW];
+    __shared__ int s_d[KLT_DW * KLT_DW];          // packed (dx, dy) int16
+    __shared__ short s_Iw[KLT_MAX_WIN * KLT_MAX_WIN];
+    __shared__ int s_dIw[KLT_MAX_WIN * KLT_MAX_WIN];
+    __shared__ uint8_t s_J[KLT_DW * KLT_DW];
+
+    const int kfid = a.kf_id ? a.kf_id[kp] : 0;
+    const KfDev& kf = a.kfs[kfid];
+
+    svo_kp2d ref;
+    float nx, ny;
+    if (a.proj_pose) {
+        // frame.kps.kps2d = project_keypoints(estimated_pose, kps3d)   (stereo_slam.cpp:73-80)
+        float pose[6];
+        for (int i = 0; i < 6; i++) pose[i] = a.proj_pose[i];
+        PoseMats pm;
+        pose_mats(pose, pm);
+        const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
+        const svo_kp2d q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+        nx = q.x; ny = q.y;
+        ref = kf.kps2d[a.kp_index[kp]];
+        if (lane == 0) {
+            a.proj_out[kp] = q;
+            if (a.ref_out) a.ref_out[kp] = ref;
+        }
+    } else {
+        ref = a.prev_pts[kp];
+        const svo_kp2d q = a.cur_pts[kp];
+        nx = q.x; ny = q.y;
+    }
+
+    const int maxLevel = min(kf.n_lk, a.n_cur) - 1;
+    const float halfWin = (win - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    double epsilon = 0.01;
+    epsilon *= epsilon;
+    int status = 1;
+    float err = 0;
+
+    for (int level = maxLevel; level >= 0; level--) {
+        const ImgView I = kf.lk[level];
+        const ImgView J = a.cur[level];
+        const float lscale = (float)(1. / (1 << level));
+        float prevx = ref.x * lscale, prevy = ref.y * lscale;
+        if (level == maxLevel) { nx = nx * lscale; ny = ny * lscale; }
+        else { nx = nx * 2.f; ny = ny * 2.f; }
+        float nextx = nx, nexty = ny;
+
+        prevx -= halfWin; prevy -= halfWin;
+        const int iprevx = cv_floor(prevx), iprevy = cv_floor(prevy);
+        if (iprevx < -win || iprevx >= I.w || iprevy < -win || iprevy >= I.h) {
+            if (level == 0) { status = 0; err = 0; }
+            continue;
+        }
+        float fa = prevx - iprevx, fb = prevy - iprevy;
+        int iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+        __syncthreads();
+        // (w+3)^2 tile of I around the window, rows iprevy-1 .., reflect-101
+        for (int i = lane; i < RW * RW; i += 64) {
+            const int r = i / RW, c = i % RW;
+            const int gy = reflect101(iprevy - 1 + r, I.h), gx = reflect101(iprevx - 1 + c, I.w);
+            s_I[r * KLT_RW + c] = I.data[(size_t)gy * I.stride + gx];
+        }
+        __syncthreads();
+        // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions; 0 outside the image
+        for (int i = lane; i < DW * DW; i += 64) {
+            const int r = i / DW, c = i % DW;
+            const int gy = iprevy + r, gx = iprevx + c;
+            int packed = 0;
+            if ((unsigned)gy < (unsigned)I.h && (unsigned)gx < (unsigned)I.w) {
+                const uint8_t* p0 = &s_I[r * KLT_RW + c];       // row gy-1, col gx-1
+                const uint8_t* p1 = p0 + KLT_RW;
+                const uint8_t* p2 = p1 + KLT_RW;
+                const int t0m = (p0[0] + p2[0]) * 3 + p1[0] * 10, t0p = (p0[2] + p2[2]) * 3 + p1[2] * 10;
+                const int t1m = p2[0] - p0[0], t1c = p2[1] - p0[1], t1p = p2[2] - p0[2];
+                const int dx = t0p - t0m;
+                const int dy = (t1p + t1m) * 3 + t1c * 10;
+                packed = (dx & 0xffff) | (dy << 16);
+            }
+            s_d[r * KLT_DW + c] = packed;
+        }
+        __syncthreads();
+        // template + covariance of derivatives
+        long long iA11 = 0, iA12 = 0, iA22 = 0;
+        {
+            int a11 = 0, a12 = 0, a22 = 0, cnt = 0;
+            for (int i = lane; i < win * win; i += 64) {
+                const int y = i / win, x = i % win;
+                const uint8_t* src = &s_I[(y + 1) * KLT_RW + x + 1];
+                const int* ds = &s_d[y * KLT_DW + x];
+                const int ival = SVO_DESCALE(src[0] * iw00 + src[1] * iw01 + src[KLT_RW] * iw10 +
+                                             src[KLT_RW + 1] * iw11, W_BITS - 5);
+                const int d00 = ds[0], d01 = ds[1], d10 = ds[KLT_DW], d11 = ds[KLT_DW + 1];
+                const int ixval = SVO_DESCALE((int)(short)d00 * iw00 + (int)(short)d01 * iw01 +
+                                              (int)(short)d10 * iw10 + (int)(short)d11 * iw11, W_BITS);
+                const int iyval = SVO_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 +
+                                              (d10 >> 16) * iw10 + (d11 >> 16) * iw11, W_BITS);
+                s_Iw[i] = (short)ival;
+                s_dIw[i] = (ixval & 0xffff) | (iyval << 16);
+                a11 += ixval * ixval; a12 += ixval * iyval; a22 += iyval * iyval;
+                if (++cnt == 16) {   // keep the per-lane partials inside int32
+                    iA11 += a11; iA12 += a12; iA22 += a22;
+                    a11 = a12 = a22 = 0; cnt = 0;
+                }
+            }
+            iA11 += a11; iA12 += a12; iA22 += a22;
+        }
+        iA11 = wave_sum_ll(iA11); iA12 = wave_sum_ll(iA12); iA22 = wave_sum_ll(iA22);
+        const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE,
+                    A22 = (float)iA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                             (2 * win * win);
+        if ((double)minEig < 1e-4 || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nextx -= halfWin; nexty -= halfWin;
+        float prevDx = 0, prevDy = 0;
+
+        for (int j = 0; j < 30; j++) {
+            const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
+            if (inextx < -win || inextx >= J.w || inexty < -win || inexty >= J.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            fa = nextx - inextx; fb = nexty - inexty;
+            iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
+            iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            __syncthreads();
+            for (int i = lane; i < DW * DW; i += 64) {
+                const int r = i / DW, c = i % DW;
+                const int gy = reflect101(inexty + r, J.h), gx = reflect101(inextx + c, J.w);
+                s_J[r * KLT_DW + c] = J.data[(size_t)gy * J.stride + gx];
+            }
+            __syncthreads();
+            long long ib1 = 0, ib2 = 0;
+            {
+                int b1 = 0, b2 = 0, cnt = 0;
+                for (int i = lane; i < win * win; i += 64) {
+                    const int y = i / win, x = i % win;
+                    const uint8_t* jp = &s_J[y * KLT_DW + x];
+                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_DW] * iw10 +
+                                                 jp[KLT_DW + 1] * iw11, W_BITS - 5) - (int)s_Iw[i];
+                    const int dI = s_dIw[i];
+                    b1 += diff * (int)(short)dI;
+                    b2 += diff * (dI >> 16);
+                    if (++cnt == 16) { ib1 += b1; ib2 += b2; b1 = b2 = 0; cnt = 0; }
+                }
+                ib1 += b1; ib2 += b2;
+            }
+            ib1 = wave_sum_ll(ib1); ib2 = wave_sum_ll(ib2);
+            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            const float dx = (float)((A12 * b2 - A22 * b1) * D);
+            const float dy = (float)((A12 * b1 - A11 * b2) * D);
+            nextx += dx; nexty += dy;
+            nx = nextx + halfWin; ny = nexty + halfWin;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && (double)fabsf(dx + prevDx) < 0.01 && (double)fabsf(dy + prevDy) < 0.01) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            prevDx = dx; prevDy = dy;
+        }
+
+        if (status && level == 0) {
+            const float npx = nx - halfWin, npy = ny - halfWin;
+            const int inx = cv_floor(npx), iny = cv_floor(npy);
+            if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
+                status = 0;
+                continue;
+            }
+            const float aa = npx - inx, bb = npy - iny;
+            iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+            iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
+            iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            __syncthreads();
+            for (int i = lane; i < DW * DW; i += 64) {
+                const int r = i / DW, c = i % DW;
+                const int gy = reflect101(iny + r, J.h), gx = reflect101(inx + c, J.w);
+                s_J[r * KLT_DW + c] = J.data[(size_t)gy * J.stride + gx];
+            }
+            __syncthreads();
+            int e = 0;
+            for (int i = lane; i < win * win; i += 64) {
+                const int y = i / win, x = i % win;
+                const uint8_t* jp = &s_J[y * KLT_DW + x];
+                const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_DW] * iw10 +
+                                             jp[KLT_DW + 1] * iw11, W_BITS - 5) - (int)s_Iw[i];
+                e += diff < 0 ? -diff : diff;
+            }
+            e = wave_sum_i(e);   // < 2^24: the float sum of |diff| is exact in any order
+            const float errval = (float)e;
+            err = errval * 1.f / (32 * win * win);
+        }
+    }
+
+    if (lane == 0) {
+        a.cur_pts[kp] = svo_kp2d{nx, ny};
+        a.status[kp] = (uint8_t)status;
+        a.err[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
+    }
+}
+
+void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream) {
+    (void)win;
+    if (max_n <= 0) return;
+    hipLaunchKernelGGL(klt_track_kernel, dim3(max_n, batch), dim3(64), 0, stream, d_args);
+}
+
+}  // namespace svo

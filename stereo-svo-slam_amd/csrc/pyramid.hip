@@ -1,0 +1,144 @@
+// pyramid.hip — P1/P2 of SURVEY §8a: the two image pyramids of
+// StereoSlam::new_image (src/lib/stereo_slam.cpp:131-140).
+//
+//  * pyr_halfsample_kernel: halfSample/createImgPyramid (stereo_slam.cpp:93-121),
+//    all levels in ONE launch. A 64x64 level-0 tile is staged in LDS and
+//    reduced level by level ((a+b+c+d)/4, truncating) — each level is written
+//    once, level 0 is read once. HBM-bound streaming kernel.
+//  * pyr_down_kernel: cv::pyrDown as used by cv::buildOpticalFlowPyramid
+//    (stereo_slam.cpp:139): separable [1 4 6 4 1], BORDER_REFLECT_101,
+//    (v+128)>>8, output ((w+1)/2, (h+1)/2). The Scharr derivative images of
+//    OpenCV's pyramid are NOT materialised: klt.hip derives them from an LDS
+//    tile, so the pyramid costs one byte written per pixel instead of five.
+#include "svo_kernels.hpp"
+
+namespace svo {
+
+// ------------------------------------------------------------------ P1
+constexpr int HS_TILE = 64;  // level-0 tile edge; yields levels up to 6 (1x1)
+
+__global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __restrict__ args) {
+    const PyrArgs& a = args[blockIdx.z];
+    __shared__ uint8_t t0[HS_TILE * HS_TILE];
+    __shared__ uint8_t t1[32 * 32];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * HS_TILE, y0 = blockIdx.y * HS_TILE;
+    const ImgView src = a.level[0];
+    if (x0 >= src.w || y0 >= src.h) return;
+
+    // stage the level-0 tile: 4 threads x 16 B per row, 64 rows
+    {
+        const int r = tid >> 2, c = (tid & 3) * 16;
+        const int gy = y0 + r, gx = x0 + c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy < src.h) {
+            const uint8_t* p = src.data + (size_t)gy * src.stride + gx;
+            if (gx + 16 <= src.w && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                v = *reinterpret_cast<const uint4*>(p);
+            } else {
+                uint8_t b[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[i] = (gx + i < src.w) ? p[i] : 0;
+                v = *reinterpret_cast<const uint4*>(b);
+            }
+        }
+        *reinterpret_cast<uint4*>(&t0[r * HS_TILE + c]) = v;
+    }
+    __syncthreads();
+
+    // level 1: 32x32 outputs, 4 per thread (one row segment of 4)
+    const int n_levels = a.n_levels;
+    if (n_levels > 1) {
+        const ImgView d = a.level[1];
+        const int r = tid >> 3, c = (tid & 7) * 4;
+        uint8_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint8_t* p = &t0[(2 * r) * HS_TILE + 2 * (c + i)];
+            o[i] = (uint8_t)((p[0] + p[1] + p[HS_TILE] + p[HS_TILE + 1]) / 4);
+            t1[r * 32 + c + i] = o[i];
+        }
+        const int gy = (y0 >> 1) + r, gx = (x0 >> 1) + c;
+        if (gy < d.h) {
+            uint8_t* q = const_cast<uint8_t*>(d.data) + (size_t)gy * d.stride + gx;
+            if (gx + 4 <= d.w && ((reinterpret_cast<uintptr_t>(q) & 3) == 0)) {
+                *reinterpret_cast<uint32_t*>(q) = *reinterpret_cast<const uint32_t*>(o);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (gx + i < d.w) q[i] = o[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // levels 2..: ping-pong between t0 (reused) and t1, one output per thread
+    uint8_t* in = t1;
+    uint8_t* out = t0;
+    int edge = 32;  // edge of `in`
+    for (int l = 2; l < n_levels && edge > 1; l++) {
+        const int oe = edge >> 1;
+        const ImgView d = a.level[l];
+        if (tid < oe * oe) {
+            const int r = tid / oe, c = tid % oe;
+            const uint8_t* p = &in[(2 * r) * edge + 2 * c];
+            const uint8_t v = (uint8_t)((p[0] + p[1] + p[edge] + p[edge + 1]) / 4);
+            out[r * oe + c] = v;
+            const int gy = (y0 >> l) + r, gx = (x0 >> l) + c;
+            if (gy < d.h && gx < d.w) const_cast<uint8_t*>(d.data)[(size_t)gy * d.stride + gx] = v;
+        }
+        __syncthreads();
+        uint8_t* tmp = in; in = out; out = tmp;
+        edge = oe;
+    }
+}
+
+// ------------------------------------------------------------------ P2
+constexpr int PD_TW = 64, PD_TH = 16;                 // output tile
+constexpr int PD_IW = 2 * PD_TW + 3, PD_IH = 2 * PD_TH + 3;  // input tile with halo
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const PyrArgs* __restrict__ args, int src_level) {
+    const PyrArgs& a = args[blockIdx.z];
+    const ImgView src = a.level[src_level];
+    const ImgView dst = a.level[src_level + 1];
+    __shared__ uint8_t in[PD_IH][PD_IW + 1];
+    __shared__ uint16_t hrow[PD_IH][PD_TW];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+    if (ox0 >= dst.w || oy0 >= dst.h) return;
+
+    for (int i = tid; i < PD_IH * PD_IW; i += 256) {
+        const int r = i / PD_IW, c = i % PD_IW;
+        const int sy = reflect101(2 * oy0 - 2 + r, src.h);
+        const int sx = reflect101(2 * ox0 - 2 + c, src.w);
+        in[r][c] = src.data[(size_t)sy * src.stride + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_IH * PD_TW; i += 256) {
+        const int r = i / PD_TW, c = i % PD_TW;
+        const uint8_t* p = &in[r][2 * c];
+        hrow[r][c] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
+    }
+    __syncthreads();
+    for (int i = tid; i < PD_TH * PD_TW; i += 256) {
+        const int r = i / PD_TW, c = i % PD_TW;
+        const int v = hrow[2 * r + 2][c] * 6 + (hrow[2 * r + 1][c] + hrow[2 * r + 3][c]) * 4 +
+                      hrow[2 * r][c] + hrow[2 * r + 4][c];
+        const int gy = oy0 + r, gx = ox0 + c;
+        if (gy < dst.h && gx < dst.w)
+            const_cast<uint8_t*>(dst.data)[(size_t)gy * dst.stride + gx] = (uint8_t)((v + 128) >> 8);
+    }
+}
+
+void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, hipStream_t stream) {
+    dim3 grid((w + HS_TILE - 1) / HS_TILE, (h + HS_TILE - 1) / HS_TILE, batch);
+    hipLaunchKernelGGL(pyr_halfsample_kernel, grid, dim3(256), 0, stream, d_args);
+}
+
+void launch_pyr_down(const PyrArgs* d_args, int batch, int src_level, int dst_w, int dst_h,
+                     hipStream_t stream) {
+    dim3 grid((dst_w + PD_TW - 1) / PD_TW, (dst_h + PD_TH - 1) / PD_TH, batch);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_args, src_level);
+}
+
+}  // namespace svo

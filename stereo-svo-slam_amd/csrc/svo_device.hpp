@@ -1,0 +1,350 @@
+// svo_device.hpp — device-side math shared by the gfx950 kernels.
+//
+// The float arithmetic follows the reference expression by expression
+// (built with -ffp-contract=off: no fused multiply-add), so per-element
+// results match a CPU evaluation of the same formulas; only the order of the
+// big reductions differs. Reference lines are cited per function
+// (paths relative to the reference repository).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "../../include/svo_types.h"
+
+namespace svo {
+
+struct ImgView {
+    const uint8_t* data;
+    int w, h, stride;
+};
+
+__host__ __device__ inline ImgView make_view(const svo_image& im) {
+    return ImgView{im.data, im.width, im.height, im.stride};
+}
+
+// ---------------------------------------------------------------- wave ops
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------- rotations
+// cv::Rodrigues (vector -> matrix) in double: PoseManager::set_pose,
+// src/lib/pose_manager.cpp:15-16, and inside cv::projectPoints,
+// src/lib/transform_keypoints.cpp:45. R(-r) is exactly the transpose.
+__device__ inline void rodrigues_d(const float r[3], double R[9]) {
+    double rx = r[0], ry = r[1], rz = r[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = 0.0;
+        R[0] = R[4] = R[8] = 1.0;
+        return;
+    }
+    double s, c;
+    sincos(theta, &s, &c);
+    const double c1 = 1.0 - c;
+    const double itheta = 1.0 / theta;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const double e = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+        double t = c * e;
+        t = t + c1 * rrt[k];
+        R[k] = t + s * r_x[k];
+    }
+}
+
+// Everything a kernel needs about one pose: R(r) in double (R(-r) = transpose),
+// the float copies PoseManager caches, and the translation.
+struct PoseMats {
+    double Rd[9];   // R(r)
+    float R[9];     // (float)R(r)      get_rotation_matrix()
+    float Ri[9];    // (float)R(-r)     get_inv_rotation_matrix()
+    float t[3];
+};
+
+__device__ inline void pose_mats(const float pose[6], PoseMats& m) {
+    const float r[3] = {pose[3], pose[4], pose[5]};
+    rodrigues_d(r, m.Rd);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            m.R[i * 3 + j] = (float)m.Rd[i * 3 + j];
+            m.Ri[i * 3 + j] = (float)m.Rd[j * 3 + i];
+        }
+    m.t[0] = pose[0]; m.t[1] = pose[1]; m.t[2] = pose[2];
+}
+
+// Matx33f * Vec3f: s = 0; s += a[k]*v[k]
+__device__ inline void mat33f_vec(const float* a, const float v[3], float out[3]) {
+    float t[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += a[i * 3 + k] * v[k];
+        t[i] = s;
+    }
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+}
+
+// project_keypoints, src/lib/transform_keypoints.cpp:11-48: translate by -t in
+// float, then cv::projectPoints(rvec = -r, tvec = 0) in double, float store.
+struct CamD {
+    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+};
+__device__ inline CamD make_camd(float fx, float fy, float cx, float cy, const svo_camera_settings& c) {
+    return CamD{(double)fx, (double)fy, (double)cx, (double)cy, (double)c.k1, (double)c.k2,
+                (double)c.p1, (double)c.p2, (double)c.k3};
+}
+__device__ inline svo_kp2d project_point(const double Rd[9], const float t[3], const CamD& c,
+                                         const svo_kp3d P) {
+    const float Xf = P.x - t[0], Yf = P.y - t[1], Zf = P.z - t[2];
+    const double X = Xf, Y = Yf, Z = Zf;
+    // rows of R(-r) are columns of R(r)
+    double x = Rd[0] * X + Rd[3] * Y + Rd[6] * Z + 0.0;
+    double y = Rd[1] * X + Rd[4] * Y + Rd[7] * Z + 0.0;
+    double z = Rd[2] * X + Rd[5] * Y + Rd[8] * Z + 0.0;
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    const double cdist = 1 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6;
+    const double xd = x * cdist + c.p1 * a1 + c.p2 * a2;
+    const double yd = y * cdist + c.p1 * a3 + c.p2 * a1;
+    svo_kp2d o;
+    o.x = (float)(xd * c.fx + c.cx);
+    o.y = (float)(yd * c.fy + c.cy);
+    return o;
+}
+
+// 2x6 Jacobian of src/lib/pose_estimator.cpp:343-344 / pose_refinement.cpp:380-381
+__device__ inline void pose_jacobian(float fx, float fy, float x, float y, float z, float J[12]) {
+    J[0] = -fx / z;  J[1] = 0;       J[2] = fx * x / (z * z);
+    J[3] = fx * x * y / (z * z);     J[4] = -fx * (1 + (x * x) / (z * z)); J[5] = fx * y / z;
+    J[6] = 0;        J[7] = -fy / z; J[8] = fy * y / (z * z);
+    J[9] = fy * (1 + (y * y) / (z * z)); J[10] = -fy * x * y / (z * z);    J[11] = -fy * x / z;
+}
+
+// exponential_map, src/include/exponential_map.hpp:12-37 (norm fixed to 1,
+// double scale factors applied to a float matrix).
+__device__ inline void exponential_map(const float twist[6], float out[6]) {
+    const float v[3] = {twist[0], twist[1], twist[2]};
+    const float w[3] = {twist[3], twist[4], twist[5]};
+    const float K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    float K2[9], M[9];
+    const float norm = 1.0f;
+    const double c1 = 1 - cos((double)norm);
+    const double c2 = norm - sin((double)norm);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += K[i * 3 + k] * K[k * 3 + j];
+            K2[i * 3 + j] = s;
+        }
+    for (int k = 0; k < 9; k++) {
+        const float e = (k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f;
+        const float t0 = e * norm;
+        const float t1 = (float)(K[k] * c1);
+        const float t2 = (float)(K2[k] * c2);
+        M[k] = (t0 + t1) + t2;
+    }
+    float t[3];
+    mat33f_vec(M, v, t);
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+    out[3] = w[0]; out[4] = w[1]; out[5] = w[2];
+}
+
+// ------------------------------------------------------------- small SVD
+// One-sided Jacobi SVD on the rows of At (OpenCV JacobiSVDImpl_<float>):
+// float data, double dot products. Reached in the reference through
+// Matx66f::inv(DECOMP_SVD) (pose_estimator.cpp:405, pose_refinement.cpp:398),
+// cv::solve(DECOMP_SVD) (depth_filter.cpp:200) and cv::KalmanFilter::correct.
+template <int M, int N>
+__device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], float (&Vt)[N][N]) {
+    const float eps = FLT_EPSILON * 2;
+    double Wd[N];
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+        for (int k = 0; k < M; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        Wd[i] = sd;
+        for (int k = 0; k < N; k++) Vt[i][k] = 0;
+        Vt[i][i] = 1;
+    }
+    const int max_iter = M > 30 ? M : 30;
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++)
+            for (int j = i + 1; j < N; j++) {
+                double a = Wd[i], p = 0, b = Wd[j];
+                for (int k = 0; k < M; k++) p += (double)At[i][k] * At[j][k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot(p, beta);
+                float c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (float)sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (int k = 0; k < M; k++) {
+                    const float t0 = c * At[i][k] + s * At[j][k];
+                    const float t1 = -s * At[i][k] + c * At[j][k];
+                    At[i][k] = t0; At[j][k] = t1;
+                    a += (double)t0 * t0; b += (double)t1 * t1;
+                }
+                Wd[i] = a; Wd[j] = b;
+                changed = true;
+                for (int k = 0; k < N; k++) {
+                    const float t0 = c * Vt[i][k] + s * Vt[j][k];
+                    const float t1 = -s * Vt[i][k] + c * Vt[j][k];
+                    Vt[i][k] = t0; Vt[j][k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+        for (int k = 0; k < M; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        Wd[i] = sqrt(sd);
+    }
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (Wd[j] < Wd[k]) j = k;
+        if (i != j) {
+            const double tw = Wd[i]; Wd[i] = Wd[j]; Wd[j] = tw;
+            for (int k = 0; k < M; k++) { const float t = At[i][k]; At[i][k] = At[j][k]; At[j][k] = t; }
+            for (int k = 0; k < N; k++) { const float t = Vt[i][k]; Vt[i][k] = Vt[j][k]; Vt[j][k] = t; }
+        }
+    }
+    for (int i = 0; i < N; i++) {
+        W[i] = (float)Wd[i];
+        const double sd = Wd[i];
+        const float s = (float)(sd > (double)FLT_MIN ? 1 / sd : 0.);
+        for (int k = 0; k < M; k++) At[i][k] *= s;
+    }
+}
+
+// Matx66f::inv(DECOMP_SVD): zeros when sigma_max < FLT_EPSILON or
+// sigma_min / sigma_max == 0, else V diag(1/w) U^T with the SVBkSb threshold.
+__device__ inline void inv_svd6(const float H[36], float Hinv[36]) {
+    float At[6][6], Vt[6][6], W[6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) At[i][j] = H[j * 6 + i];
+    jacobi_svd<6, 6>(At, W, Vt);
+    for (int i = 0; i < 36; i++) Hinv[i] = 0;
+    double threshold = 0;
+    for (int i = 0; i < 6; i++) threshold += W[i];
+    threshold *= (float)(DBL_EPSILON * 2);
+    for (int i = 0; i < 6; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double buffer[6];
+        for (int j = 0; j < 6; j++) buffer[j] = At[i][j] * wi;
+        for (int r = 0; r < 6; r++) {
+            const float sv = Vt[i][r];
+            for (int j = 0; j < 6; j++) Hinv[r * 6 + j] = (float)(Hinv[r * 6 + j] + sv * buffer[j]);
+        }
+    }
+    const bool ok = W[0] >= FLT_EPSILON ? (W[5] / W[0] != 0) : false;
+    if (!ok)
+        for (int i = 0; i < 36; i++) Hinv[i] = 0;
+}
+
+// cv::solve(A[3x2], b, x, DECOMP_SVD), src/lib/depth_filter.cpp:194-200
+__device__ inline void solve_svd_3x2(const float A[6], const float b[3], float x[2]) {
+    float At[2][3], Vt[2][2], W[2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) At[i][j] = A[j * 2 + i];
+    jacobi_svd<3, 2>(At, W, Vt);
+    x[0] = x[1] = 0;
+    double threshold = ((double)W[0] + (double)W[1]) * (float)(DBL_EPSILON * 2);
+    for (int i = 0; i < 2; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < 3; j++) s += At[i][j] * b[j];
+        s *= wi;
+        for (int j = 0; j < 2; j++) x[j] = (float)(x[j] + s * Vt[i][j]);
+    }
+}
+
+// 1-state cv::KalmanFilter predict()+correct(meas) with A = H = 1
+// (src/lib/depth_filter.cpp:202-215); gain through the 1x1 SVD solve.
+__device__ inline void kf1_update(float& x, float& P, float Q, float R, float meas) {
+    const float statePre = (float)((double)1.0f * (double)x);
+    const float temp1 = (float)((double)1.0f * (double)P);
+    const float errorCovPre = (float)((double)temp1 * (double)1.0f + (double)Q);
+    const float temp2 = (float)((double)1.0f * (double)errorCovPre);
+    const float temp3 = (float)((double)temp2 * (double)1.0f + (double)R);
+    // 1x1 Jacobi SVD: w = |a|, u = a * (float)(1/w), v = 1
+    float gain = 0;
+    {
+        const double sd = sqrt((double)temp3 * temp3);
+        const float w = (float)sd;
+        const float u = temp3 * (float)(sd > (double)FLT_MIN ? 1 / sd : 0.);
+        const double threshold = (double)w * (float)(DBL_EPSILON * 2);
+        if (!(fabs((double)w) <= threshold)) {
+            const double wi = 1 / (double)w;
+            double s = 0;
+            s += u * temp2;
+            s *= wi;
+            gain = (float)(0.0f + s * 1.0f);
+        }
+    }
+    const float temp5 = meas - (float)((double)1.0f * (double)statePre);
+    x = (float)((double)gain * (double)temp5 + (double)statePre);
+    P = (float)(-((double)gain * (double)temp2) + (double)errorCovPre);
+}
+
+// get_patch_sum, src/lib/pose_estimator.cpp:82-112 (3x3 taps = area sum of a
+// 2x2 box centred at `c`; callers guard the bounds)
+__device__ inline float patch_sum(const uint8_t* img, int stride, float cx, float cy) {
+    const float sx = cx - 0.5f, sy = cy - 0.5f;
+    const float fx_ = floorf(sx), fy_ = floorf(sy);
+    const int ipx = (int)fx_, ipy = (int)fy_;
+    const float x2 = sx - (float)ipx, y2 = sy - (float)ipy;
+    const float x1 = 1.0f - x2, y1 = 1.0f - y2;
+    const uint8_t* s1 = img + (long)ipy * stride + ipx;
+    const uint8_t* s2 = s1 + stride;
+    const uint8_t* s3 = s2 + stride;
+    const float intensity = x1 * y1 * (float)s1[0] + y1 * (float)s1[1] + x2 * y1 * (float)s1[2] +
+                            x1 * (float)s2[0] + (float)s2[1] + x2 * (float)s2[2] +
+                            x1 * y2 * (float)s3[0] + y2 * (float)s3[1] + x2 * y2 * (float)s3[2];
+    return intensity;
+}
+
+__device__ inline int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+}  // namespace svo

@@ -1,0 +1,132 @@
+// svo_kernels.hpp — argument blocks and launchers of the gfx950 kernels.
+//
+// Every kernel takes a device array of per-sequence argument blocks and uses
+// blockIdx.{z|y} as the sequence index, so B independent sequences (one
+// StereoSlam instance each) share every launch. A single sequence is B = 1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "svo_device.hpp"
+
+namespace svo {
+
+// ---------------------------------------------------------------- pyramids
+struct PyrArgs {
+    ImgView level[SVO_MAX_PYRAMID_LEVELS];  // [0] = input, [1..] = outputs
+    int n_levels;
+};
+void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, hipStream_t stream);
+void launch_pyr_down(const PyrArgs* d_args, int batch, int src_level, int dst_w, int dst_h,
+                     hipStream_t stream);
+
+// ------------------------------------------------- sparse image alignment
+struct SiaArgs {
+    ImgView prev[SVO_MAX_PYRAMID_LEVELS];
+    ImgView cur[SVO_MAX_PYRAMID_LEVELS];
+    svo_camera_settings cam;
+    const int* n_ptr;             // number of keypoints (device)
+    const svo_kp2d* kps2d;        // previous frame, full resolution
+    const svo_kp3d* kps3d;
+    const uint32_t* flags;        // SVO_IGNORE_TEMPORARY => not used
+    const float* pose_guess;      // [6]
+    float* pose_out;              // [6]
+    float* cost_out;              // [1]
+    svo_gn_trace* trace;          // [SVO_MAX_PYRAMID_LEVELS] or null
+    float4* cache;                // workspace [cap*16]: per (kp,px) {gx, gy, ps_prev, i1_prev}
+    float* kp_ws;                 // workspace [cap*8]: per kp {Gxx, Gxy, Gyy, krefx, krefy, active, -, -}
+    float* dbg_H;                 // optional [36+6+6]: H, b, step of the first get_gradient of `dbg_level`
+    int dbg_level;
+    int cap;
+};
+void launch_sia(const SiaArgs* d_args, int batch, size_t lds_bytes, int cap, hipStream_t stream);
+size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap);
+
+// --------------------------------------------------------------------- KLT
+struct KfDev {                    // one keyframe as the device sees it
+    ImgView lk[SVO_LK_LEVELS];    // Gaussian pyramid (unpadded)
+    int n_lk;
+    float pose[6];
+    svo_kp2d* kps2d;              // keyframe->kps.kps2d
+    svo_kp3d* kps3d;              // keyframe->kps.kps3d (updated by the depth filter)
+    uint32_t* flags;              // ignore_temporary / ignore_completely mirror
+    int* outlier_count;
+    int* inlier_count;
+    int n;
+};
+
+struct KltArgs {
+    const KfDev* kfs;             // keyframe table
+    const int* kf_id;             // [n] origin keyframe of each point (null: all 0)
+    ImgView cur[SVO_LK_LEVELS];
+    int n_cur;
+    const int* n_ptr;
+    const svo_kp2d* prev_pts;     // [n] reference positions
+    svo_kp2d* cur_pts;            // [n] in: initial flow, out: tracked
+    uint8_t* status;              // [n]
+    float* err;                   // [n]
+    int win;
+    // optional fused projection (tracker path): cur_pts = project(pose, kps3d) first
+    const float* proj_pose;       // [6] or null
+    const svo_kp3d* kps3d;
+    svo_kp2d* proj_out;           // [n] projected positions (frame.kps.kps2d before the merge)
+    const int* kp_index;          // [n] with proj_pose: prev_pts is gathered from kfs[kf_id].kps2d[kp_index]
+    svo_kp2d* ref_out;            // [n] gathered reference points (or null)
+    svo_camera_settings cam;
+};
+void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream);
+
+// ------------------------------------------- merge + reprojection GN (B1,B3)
+struct ReprojArgs {
+    svo_camera_settings cam;
+    const int* n_ptr;
+    svo_kp2d* kps2d;              // in: projected, out: merged
+    const svo_kp3d* kps3d;
+    uint32_t* flags;
+    const svo_kp2d* tracked;      // null: skip the merge
+    const float* err;
+    const float* pose_in;
+    float* pose_out;
+    float* cost_out;
+    svo_gn_trace* trace;          // [1] or null
+};
+void launch_reproj(const ReprojArgs* d_args, int batch, hipStream_t stream);
+
+// ------------------------------------------------------------ depth filter
+struct SsdArgs {
+    ImgView left, right;
+    const int* n_ptr;
+    const svo_kp2d* kps2d;
+    float* disparity;
+    int win, search_x, search_y, clamp_half;
+    int first;                    // process kps [first, n)
+};
+void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream);
+
+struct FilterArgs {
+    svo_camera_settings cam;
+    const int* n_ptr;
+    const float* frame_pose;      // [6] refined pose
+    svo_kp2d* kps2d;              // in: merged positions; out (if reproject): project(pose, kps3d)
+    svo_kp3d* kps3d;
+    uint32_t* flags;
+    int* outlier_count;
+    int* inlier_count;
+    float* kf_inv_depth;
+    float* kf_variance;
+    const float* disparity;
+    // explicit per-point references (stage API) ...
+    const svo_kp3d* ref3d;
+    const svo_kp2d* ref2d;
+    const float* kf_pose;         // [n*6]
+    // ... or the keyframe table (tracker): gathers refs and writes results back
+    KfDev* kfs;
+    const int* kf_id;
+    const int* kp_index;
+    int do_outlier_check, do_update, do_flags, do_reproject;
+    int width, height;
+    int* inside_count;            // keyframe_needed numerator (or null)
+};
+void launch_filter(const FilterArgs* d_args, int batch, hipStream_t stream);
+
+}  // namespace svo
