@@ -93,6 +93,67 @@ int svo_depth_filter_update(svo_handle *h, const svo_kp2d *kps2d, svo_kp3d *kps3
                             float *kf_inv_depth, float *kf_variance,
                             int do_outlier_check, int do_update);
 
+/* ---- whole tracker: StereoSlam (src/include/stereo_slam.hpp:27-79) --------
+ * One svo_ctx owns `n_sequences` independent StereoSlam instances that advance
+ * in lock-step and share every kernel launch (sequence = a grid dimension);
+ * n_sequences = 1 is the drop-in for one StereoSlam object. A ctx is
+ * single-caller; different ctxs are independent (own stream, own counters —
+ * the reference's process-global keyframe counters, keyframe_manager.cpp:8 and
+ * depth_calculator.cpp:135, are per sequence here). */
+typedef struct svo_ctx svo_ctx;
+
+enum { SVO_MEM_HOST = 0, SVO_MEM_DEVICE = 1 };
+
+/* StereoSlam::StereoSlam(const CameraSettings&)         src/lib/stereo_slam.cpp:29-41 */
+int svo_ctx_create(const svo_camera_settings *cam, int width, int height, int n_sequences,
+                   int device, svo_ctx **out);
+int svo_ctx_destroy(svo_ctx *ctx);
+
+/* StereoSlam::new_image(left, right, time_stamp)        src/lib/stereo_slam.cpp:123-271
+ * for every sequence of the ctx: left[s]/right[s] point to 8-bit images of the
+ * ctx size with `stride` bytes per row, in host (SVO_MEM_HOST) or device memory.
+ * The images are copied; the caller may reuse its buffers on return. Returns
+ * after the frame is complete (like the reference). */
+int svo_new_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *const *right,
+                   int stride, const float *time_stamps, int mem);
+/* n_sequences == 1, host memory: the exact shape of StereoSlam::new_image */
+int svo_new_image(svo_ctx *ctx, const uint8_t *left, int left_stride, const uint8_t *right,
+                  int right_stride, int width, int height, float time_stamp);
+
+/* Frame::pose of the current frame (get_frame, src/lib/stereo_slam.cpp:278-284) */
+int svo_get_pose(svo_ctx *ctx, int seq, float pose[6]);
+/* Frame::kps of the current frame; returns the count in *n (copies min(n, cap)) */
+int svo_get_frame_keypoints(svo_ctx *ctx, int seq, svo_kp2d *kps2d, svo_kp3d *kps3d,
+                            svo_kp_info *info, int cap, int *n);
+/* get_keyframes / get_keyframe (src/lib/stereo_slam.cpp:273-289) */
+int svo_get_keyframe_count(svo_ctx *ctx, int seq, int *count);
+int svo_get_keyframe(svo_ctx *ctx, int seq, int id, svo_kp2d *kps2d, svo_kp3d *kps3d,
+                     svo_kp_info *info, float pose[6], int cap, int *n);
+/* get_trajectory (src/lib/stereo_slam.cpp:291-294) */
+int svo_get_trajectory(svo_ctx *ctx, int seq, svo_pose *out, int cap, int *n);
+/* StereoSlam::update_pose (12-state Kalman)             src/lib/stereo_slam.cpp:296-359 */
+int svo_update_pose(svo_ctx *ctx, int seq, const float pose[6], const float speed[6],
+                    const float pose_var[6], const float speed_var[6], double dt,
+                    float filtered[6]);
+
+/* per-frame diagnostics of the last svo_new_images call */
+typedef struct svo_frame_stats {
+    int32_t frame_id;
+    int32_t is_keyframe;
+    int32_t n_keypoints;
+    int32_t n_keyframes;
+    int32_t inside_count;
+    int32_t overflow;
+    float   pose_sia[6];
+    float   pose_refined[6];
+    float   sia_cost, reproj_cost;
+    float   sia_ms;             /* device time of the sparse-alignment kernel (timing on) */
+    svo_gn_trace sia_trace[SVO_MAX_PYRAMID_LEVELS];
+    svo_gn_trace reproj_trace;
+} svo_frame_stats;
+int svo_get_frame_stats(svo_ctx *ctx, int seq, svo_frame_stats *out);
+int svo_ctx_enable_timing(svo_ctx *ctx, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,8 +22,9 @@ constexpr int SSD_MAX_MATCH = 65 * 17;
 
 __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
     const SsdArgs& a = args[blockIdx.y];
+    if (a.enable && !*a.enable) return;
     const int n = *a.n_ptr;
-    const int kp = a.first + (int)blockIdx.x;
+    const int kp = a.first + (a.first_ptr ? *a.first_ptr : 0) + (int)blockIdx.x;
     if (kp >= n) return;
     const int tid = threadIdx.x;
 

@@ -1,0 +1,407 @@
+// keyframe.hip — the per-frame bookkeeping kernels of StereoSlam::new_image
+// and keyframe creation, all on the device so that a frame never needs the
+// image back on the host:
+//
+//  * compact_kernel: remove_outliers (src/lib/stereo_slam.cpp:43-56) and
+//    find_bad_keypoints (src/lib/depth_calculator.cpp:67-86): order-preserving
+//    stream compaction of the SoA keypoint set (workgroup prefix scan).
+//  * kf_detect_kernel: CornerDetector::detect_keypoints
+//    (src/lib/corner_detector.cpp:13-79) on every pyramid level at once:
+//    cv::FAST(6, nonmax) restated as score + 3x3 NMS on an LDS tile per grid
+//    cell, cv::Sobel(dx, 8U) edgelets as the fall-back, first-best selection in
+//    the reference's scan orders.
+//  * kf_select_merge_kernel: select_best_keypoints (:37-65, index-wise across
+//    levels as the reference does) and merge_keypoints (:88-130, with the
+//    swapped grid arguments of :179-180).
+//  * kf_init_kernel: the depth / filter initialisation of
+//    DepthCalculator::calculate_depth (:241-289), the copy into the new
+//    keyframe (keyframe_manager.cpp:15-32) and the ignore_temporary rules of
+//    stereo_slam.cpp:157-159 and :237-245.
+#include "svo_kernels.hpp"
+#include "svo_tracker.hpp"
+
+namespace svo {
+
+// ------------------------------------------------------------ prefix scan
+// exclusive scan of one int per thread over the workgroup (1024 threads)
+__device__ inline int block_exclusive_scan(int v, int* s_wave /*[16]*/, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+        const int x = s_wave[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+__device__ inline void copy_kp(const KpsDev& d, int di, const KpsDev& s, int si) {
+    d.kps2d[di] = s.kps2d[si];
+    d.kps3d[di] = s.kps3d[si];
+    d.flags[di] = s.flags[si];
+    d.kf_id[di] = s.kf_id[si];
+    d.kp_index[di] = s.kp_index[si];
+    d.outl[di] = s.outl[si];
+    d.inl[di] = s.inl[si];
+    d.kfx[di] = s.kfx[si];
+    d.kfP[di] = s.kfP[si];
+    d.score[di] = s.score[si];
+    d.level_type[di] = s.level_type[si];
+    d.color[di] = s.color[si];
+}
+
+__global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __restrict__ args) {
+    const CompactArgs& a = args[blockIdx.x];
+    if (a.enable && !*a.enable) return;
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x;
+    const int n = *a.src.n;
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; i++) {
+        const uint32_t f = a.src.flags[i];
+        bool keep;
+        if (a.mode == 0) {
+            keep = !(f & SVO_IGNORE_COMPLETELY);
+        } else {
+            const svo_kp2d k = a.src.kps2d[i];
+            keep = !((k.x < 0) || (k.y < 0) || (k.x > a.width) || (k.y > a.height) ||
+                     (f & SVO_IGNORE_COMPLETELY) || (f & SVO_IGNORE_DURING_REFINEMENT));
+        }
+        cnt += keep ? 1 : 0;
+    }
+    int total;
+    int pos = block_exclusive_scan(cnt, s_wave, total);
+    for (int i = i0; i < i1; i++) {
+        const uint32_t f = a.src.flags[i];
+        bool keep;
+        if (a.mode == 0) {
+            keep = !(f & SVO_IGNORE_COMPLETELY);
+        } else {
+            const svo_kp2d k = a.src.kps2d[i];
+            keep = !((k.x < 0) || (k.y < 0) || (k.x > a.width) || (k.y > a.height) ||
+                     (f & SVO_IGNORE_COMPLETELY) || (f & SVO_IGNORE_DURING_REFINEMENT));
+        }
+        if (keep) copy_kp(a.dst, pos++, a.src, i);
+    }
+    if (tid == 0) *a.dst.n = total;
+}
+
+void launch_compact(const CompactArgs* d_args, int batch, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, stream, d_args);
+}
+
+// --------------------------------------------------------------- detection
+constexpr int DET_MAX_CW = 96, DET_MAX_CH = 64;
+constexpr int DET_TW = DET_MAX_CW + 8, DET_TH = DET_MAX_CH + 8;   // cell + 4 px halo
+constexpr int DET_RW = DET_MAX_CW + 2, DET_RH = DET_MAX_CH + 2;   // raw scores: cell + 1 px
+
+__constant__ int c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// cv::FAST TYPE_9_16: corner test + cornerScore<16> (OpenCV fast.cpp / fast_score.cpp)
+__device__ inline int fast_score(const uint8_t* p, int stride, int threshold) {
+    int d[25];
+    const int v = p[0];
+#pragma unroll
+    for (int k = 0; k < 25; k++) d[k] = v - (int)p[c_ring_dy[k & 15] * stride + c_ring_dx[k & 15]];
+    // corner test: 9 contiguous darker (d > t) or brighter (d < -t) ring pixels
+    bool corner = false;
+    int cd = 0, cb = 0;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        cd = (d[k] > threshold) ? cd + 1 : 0;
+        cb = (d[k] < -threshold) ? cb + 1 : 0;
+        corner = corner || cd > 8 || cb > 8;
+    }
+    if (!corner) return 0;
+    int a0 = threshold;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(d[k + 1], d[k + 2]);
+        a = min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = min(a, d[k + 4]); a = min(a, d[k + 5]); a = min(a, d[k + 6]);
+        a = min(a, d[k + 7]); a = min(a, d[k + 8]);
+        a0 = max(a0, min(a, d[k]));
+        a0 = max(a0, min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int b = max(d[k + 1], d[k + 2]);
+        b = max(b, d[k + 3]); b = max(b, d[k + 4]); b = max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = max(b, d[k + 6]); b = max(b, d[k + 7]); b = max(b, d[k + 8]);
+        b0 = min(b0, max(b, d[k]));
+        b0 = min(b0, max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+__global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __restrict__ args) {
+    const DetectArgs& a = args[blockIdx.z];
+    if (a.enable && !*a.enable) return;
+    const int level = blockIdx.y;
+    if (level >= a.n_levels) return;
+    const ImgView im = a.level[level];
+    const int gw = a.grid_w >> level, gh = a.grid_h >> level;
+    if (gw <= 0 || gh <= 0 || gw > DET_MAX_CW || gh > DET_MAX_CH) return;
+    const int ncx = im.w / gw, ncy = max(im.h / gh, 1);
+    const int cell = blockIdx.x;
+    if (cell >= ncx * ncy) return;
+    const int cxi = cell % ncx, cyi = cell / ncx;
+    const int left = cxi * gw, top = cyi * gh;
+    const int tid = threadIdx.x;
+
+    __shared__ uint8_t s_t[DET_TH * DET_TW];
+    __shared__ uint8_t s_raw[DET_RH * DET_RW];
+    __shared__ unsigned s_key[4];
+
+    const int tw = gw + 8, th = gh + 8;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int r = i / tw, c = i % tw;
+        const int gy = reflect101(top - 4 + r, im.h), gx = reflect101(left - 4 + c, im.w);
+        s_t[r * DET_TW + c] = im.data[(size_t)gy * im.stride + gx];
+    }
+    __syncthreads();
+    // raw FAST scores on the cell + 1 px (0 outside the detector's 3 px border)
+    const int rw = gw + 2, rh = gh + 2;
+    for (int i = tid; i < rw * rh; i += 256) {
+        const int r = i / rw, c = i % rw;
+        const int gy = top - 1 + r, gx = left - 1 + c;
+        int sc = 0;
+        if (gx >= 3 && gx < im.w - 3 && gy >= 3 && gy < im.h - 3)
+            sc = fast_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+        s_raw[r * DET_RW + c] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // NMS + first-best in row-major order
+    unsigned best = 0;
+    for (int i = tid; i < gw * gh; i += 256) {
+        const int r = i / gw, c = i % gw;
+        if (top + r >= im.h) continue;
+        const uint8_t* q = &s_raw[(r + 1) * DET_RW + c + 1];
+        const int sc = q[0];
+        if (sc && sc > q[1] && sc > q[-1] && sc > q[-DET_RW - 1] && sc > q[-DET_RW] &&
+            sc > q[-DET_RW + 1] && sc > q[DET_RW - 1] && sc > q[DET_RW] && sc > q[DET_RW + 1]) {
+            const unsigned key = ((unsigned)sc << 20) | (0xFFFFFu - (unsigned)i);
+            best = max(best, key);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+    if ((tid & 63) == 0) s_key[tid >> 6] = best;
+    __syncthreads();
+    best = max(max(s_key[0], s_key[1]), max(s_key[2], s_key[3]));
+    int type = SVO_KP_FAST;
+    float score, px, py;
+    if (best) {
+        const int i = (int)(0xFFFFFu - (best & 0xFFFFFu));
+        score = (float)(best >> 20);
+        px = (float)(left + i % gw);
+        py = (float)(top + i / gw);
+    } else {
+        // edgelet: max of saturate_u8(Sobel dx), scan order x outer / y inner
+        __syncthreads();
+        unsigned eb = 0;
+        for (int i = tid; i < gw * gh; i += 256) {
+            const int c = i / gh, r = i % gh;        // order index = x*gh + y
+            const uint8_t* p1 = &s_t[(r + 4) * DET_TW + c + 4];
+            const uint8_t* p0 = p1 - DET_TW;
+            const uint8_t* p2 = p1 + DET_TW;
+            int v = (p0[1] - p0[-1]) + 2 * (p1[1] - p1[-1]) + (p2[1] - p2[-1]);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            const unsigned key = ((unsigned)v << 20) | (0xFFFFFu - (unsigned)i);
+            eb = max(eb, key);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) eb = max(eb, (unsigned)__shfl_xor((int)eb, o, 64));
+        if ((tid & 63) == 0) s_key[tid >> 6] = eb;
+        __syncthreads();
+        eb = max(max(s_key[0], s_key[1]), max(s_key[2], s_key[3]));
+        const int i = (int)(0xFFFFFu - (eb & 0xFFFFFu));
+        score = (float)(eb >> 20);
+        px = (float)(left + i / gh);
+        py = (float)(top + i % gh);
+        type = SVO_KP_EDGELET;
+    }
+    if (tid == 0) {
+        DetCell o;
+        o.x = px; o.y = py; o.score = score; o.type = type;
+        a.out[(size_t)level * a.max_cells + cell] = o;
+        if (cell == 0) a.n_out[level] = ncx * ncy;
+    }
+}
+
+void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, hipStream_t stream) {
+    hipLaunchKernelGGL(kf_detect_kernel, dim3(max_cells, n_levels, batch), dim3(256), 0, stream, d_args);
+}
+
+// --------------------------------------------------------- select + merge
+__global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* __restrict__ args) {
+    const MergeArgs& a = args[blockIdx.x];
+    if (a.enable && !*a.enable) return;
+    const int tid = threadIdx.x;
+    const int nsel = a.n_det[0];
+    const int n_old = *a.kps.n;
+    const int mcw = a.cam.grid_height, mch = a.cam.grid_width;   // swapped on purpose (:179-180)
+    const int ncx = (a.width + mcw - 1) / mcw, ncy = (a.height + mch - 1) / mch;
+    const int ncells = ncx * ncy;
+
+    // select_best_keypoints: entry j of level i is compared with entry j of level 0
+    for (int j = tid; j < nsel; j += 1024) {
+        DetCell s = a.det[j];
+        int lvl = 0;
+        for (int i = 1; i < a.n_levels; i++) {
+            if (j >= a.n_det[i]) continue;   // the reference would read out of bounds
+            const DetCell c = a.det[(size_t)i * a.max_cells + j];
+            if (s.type == SVO_KP_FAST && c.type == SVO_KP_EDGELET) continue;
+            if (s.type == c.type && s.score > c.score) continue;
+            s = c;
+            s.x *= (float)(1 << i);
+            s.y *= (float)(1 << i);
+            lvl = i;
+        }
+        a.sel[j] = s;
+        a.sel_level[j] = lvl;
+        a.sel_cell[j] = -1;
+    }
+    for (int c = tid; c < ncells; c += 1024) a.occupied[c] = 0;
+    __syncthreads();
+    // cells that already hold a keypoint (strictly inside)
+    for (int i = tid; i < n_old; i += 1024) {
+        const svo_kp2d k = a.kps.kps2d[i];
+        if (!(k.x > 0 && k.y > 0)) continue;
+        const int xi = (int)floorf(k.x) / mcw, yi = (int)floorf(k.y) / mch;
+        if (xi >= ncx || yi >= ncy) continue;
+        const int l = xi * mcw, t = yi * mch;
+        if (k.x > l && k.x < l + mcw && k.y > t && k.y < t + mch) a.occupied[xi * ncy + yi] = 1;
+    }
+    __syncthreads();
+    for (int j = tid; j < nsel; j += 1024) {
+        const DetCell s = a.sel[j];
+        if (!(s.x > 0 && s.y > 0)) continue;
+        const int xi = (int)floorf(s.x) / mcw, yi = (int)floorf(s.y) / mch;
+        if (xi >= ncx || yi >= ncy) continue;
+        const int l = xi * mcw, t = yi * mch;
+        if (s.x > l && s.x < l + mcw && s.y > t && s.y < t + mch && !a.occupied[xi * ncy + yi])
+            a.sel_cell[j] = xi * ncy + yi;
+    }
+    __syncthreads();
+    // output order of the reference: cells x-outer / y-inner, candidates by index
+    __shared__ int s_cnt;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int j = tid; j < nsel; j += 1024) {
+        const int cj = a.sel_cell[j];
+        if (cj < 0) continue;
+        int pos = 0;
+        for (int q = 0; q < nsel; q++) {
+            const int cq = a.sel_cell[q];
+            pos += (cq >= 0 && (cq < cj || (cq == cj && q < j))) ? 1 : 0;
+        }
+        atomicAdd(&s_cnt, 1);
+        const int di = n_old + pos;
+        if (di < a.cap) {
+            const DetCell s = a.sel[j];
+            a.kps.kps2d[di] = svo_kp2d{s.x, s.y};
+            a.kps.score[di] = s.score;
+            a.kps.level_type[di] = a.sel_level[j] | (s.type << 8);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n_new = s_cnt;
+        if (n_old + n_new > a.cap) { n_new = a.cap - n_old; *a.overflow = 1; }
+        *a.old_count = n_old;
+        *a.kps.n = n_old + n_new;
+    }
+}
+
+void launch_select_merge(const MergeArgs* d_args, int batch, hipStream_t stream) {
+    hipLaunchKernelGGL(kf_select_merge_kernel, dim3(batch), dim3(1024), 0, stream, d_args);
+}
+
+// ------------------------------------------------------------------- init
+__global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restrict__ args) {
+    const KfInitArgs& a = args[blockIdx.x];
+    if (a.enable && !*a.enable) return;
+    const int tid = threadIdx.x;
+    const int n = *a.kps.n, old_count = *a.old_count;
+    __shared__ PoseMats pm;
+    __shared__ int s_cnt[4];
+    float pose[6];
+    for (int i = 0; i < 6; i++) pose[i] = a.first_frame ? 0.f : a.frame_pose[i];
+    if (tid == 0) pose_mats(pose, pm);
+    __syncthreads();
+    const float fx = a.cam.fx, fy = a.cam.fy, cx = a.cam.cx, cy = a.cam.cy, baseline = a.cam.baseline;
+    const uint32_t lcg0 = *a.color_lcg;
+    for (int i = old_count + tid; i < n; i += 256) {
+        const svo_kp2d kp = a.kps.kps2d[i];
+        const float disparity = a.disparity[i];
+        const float _z = baseline / fmaxf(0.5f, disparity);
+        const float _x = (kp.x - cx) / fx * _z;
+        const float _y = (kp.y - cy) / fy * _z;
+        float loc[3] = {_x, _y, _z};
+        mat33f_vec(pm.R, loc, loc);
+        a.kps.kps3d[i] = svo_kp3d{loc[0] + pm.t[0], loc[1] + pm.t[1], loc[2] + pm.t[2]};
+        uint32_t st = lcg0;
+        for (int q = old_count; q <= i; q++) st = st * 1664525u + 1013904223u;
+        a.kps.color[i] = (st >> 8) & 0xFFFFFFu;
+        a.kps.kf_id[i] = a.new_kf_id;
+        a.kps.kp_index[i] = i;
+        a.kps.flags[i] = SVO_IGNORE_TEMPORARY;
+        a.kps.inl[i] = 0;
+        a.kps.outl[i] = 0;
+        const float deviation = (float)(0.5 / (double)(baseline / fx));
+        a.kps.kfP[i] = deviation * deviation;
+        a.kps.kfx[i] = 1 / _z;
+    }
+    __syncthreads();
+    // keyframe.kps = frame.kps; keyframe.pose = frame.pose (keyframe_manager.cpp:27-29)
+    KfDev& kf = a.kfs[a.new_kf_id];
+    int not_temp = 0;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t f = a.kps.flags[i];
+        kf.kps2d[i] = a.kps.kps2d[i];
+        kf.kps3d[i] = a.kps.kps3d[i];
+        kf.flags[i] = f;
+        kf.outlier_count[i] = a.kps.outl[i];
+        kf.inlier_count[i] = a.kps.inl[i];
+        not_temp += (f & SVO_IGNORE_TEMPORARY) ? 0 : 1;
+    }
+    not_temp = wave_sum_i(not_temp);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = not_temp;
+    __syncthreads();
+    not_temp = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tid == 0) {
+        kf.n = n;
+        for (int i = 0; i < 6; i++) kf.pose[i] = pose[i];
+        uint32_t st = lcg0;
+        for (int q = old_count; q < n; q++) st = st * 1664525u + 1013904223u;
+        *a.color_lcg = st;
+        *a.n_out = n;
+    }
+    // stereo_slam.cpp:157-159 (first frame) and :237-245 (too few usable points)
+    const bool clear_all = a.first_frame || ((size_t)not_temp < (size_t)n / 4);
+    if (clear_all)
+        for (int i = tid; i < n; i += 256) a.kps.flags[i] &= ~(uint32_t)SVO_IGNORE_TEMPORARY;
+}
+
+void launch_kf_init(const KfInitArgs* d_args, int batch, hipStream_t stream) {
+    hipLaunchKernelGGL(kf_init_kernel, dim3(batch), dim3(256), 0, stream, d_args);
+}
+
+}  // namespace svo

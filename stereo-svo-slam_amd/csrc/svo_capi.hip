@@ -25,6 +25,15 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// shared with svo_ctx.hip
+int svo_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \

@@ -1,0 +1,821 @@
+// svo_ctx.hip — the tracker behind the C ABI: StereoSlam::new_image
+// (src/lib/stereo_slam.cpp:123-271) for B sequences in lock-step.
+//
+// Host side = bookkeeping only: image-set pool, argument blocks, the 12-state
+// pose Kalman filter (stereo_slam.cpp:296-359) and the keyframe decision. All
+// image and keypoint work runs in the kernels of pyramid/sia/klt/reproj/depth/
+// keyframe.hip; a tracked frame is nine launches on one stream, one blocking
+// read-back of the result block, and (only when a keyframe is due) a second
+// batch of five launches.
+//
+// HBM layout per sequence:
+//   image sets  : left halfSample pyramid | right level 0 | Gaussian levels 1,2
+//                 (rows padded to 64 B). The current, the previous and every
+//                 keyframe's set stay resident (288 GB: ~1 MB per 752x480 set).
+//   keypoints   : two SoA sets (KpsDev) ping-ponged by the order-preserving
+//                 compactions; per-point scratch (tracked, err, disparity).
+//   keyframes   : table of KfDev records + per-keyframe SoA copies.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/svo_hip.h"
+#include "svo_tracker.hpp"
+
+using namespace svo;
+
+int svo_set_error(int code, const char* fmt, ...);   // svo_capi.hip
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return svo_set_error(SVO_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                                 hipGetErrorString(e_), __FILE__, __LINE__);             \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------ 12-state pose filter
+// cv::KalmanFilter(12,12) as configured in the StereoSlam ctor
+// (src/lib/stereo_slam.cpp:29-41) and driven by update_pose (:296-359).
+// cv::gemm on float data: double accumulation, float store; the gain comes
+// out of cv::solve(DECOMP_SVD) (Jacobi SVD, svo_device.hpp).
+struct PoseFilter {
+    static constexpr int N = 12;
+    float statePre[N], statePost[N];
+    float A[N * N], Hm[N * N], Q[N * N], R[N * N];
+    float errorCovPre[N * N], errorCovPost[N * N], gain[N * N];
+
+    static void identity(float* m, float v) {
+        std::memset(m, 0, sizeof(float) * N * N);
+        for (int i = 0; i < N; i++) m[i * N + i] = v;
+    }
+    void init() {
+        std::memset(this, 0, sizeof(*this));
+        identity(A, 1.f); identity(Hm, 1.f); identity(Q, 100.f); identity(R, 1.f);
+        identity(errorCovPost, 1.f);
+    }
+    static void gemm(const float* a, const float* b, bool bt, double alpha, const float* c,
+                     double beta, float* d, int m, int k, int n) {
+        float tmp[N * N];
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < n; j++) {
+                double s = 0;
+                for (int p = 0; p < k; p++)
+                    s += (double)a[i * k + p] * (double)(bt ? b[j * k + p] : b[p * n + j]);
+                s *= alpha;
+                if (c) s += (double)c[i * n + j] * beta;
+                tmp[i * n + j] = (float)s;
+            }
+        std::memcpy(d, tmp, sizeof(float) * m * n);
+    }
+    static void solve_svd(const float* Am, const float* B, float* X) {
+        float At[N][N], Vt[N][N], W[N];
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) At[i][j] = Am[j * N + i];
+        jacobi_svd<N, N>(At, W, Vt);
+        for (int i = 0; i < N * N; i++) X[i] = 0;
+        double threshold = 0;
+        for (int i = 0; i < N; i++) threshold += W[i];
+        threshold *= (float)(DBL_EPSILON * 2);
+        for (int i = 0; i < N; i++) {
+            double wi = W[i];
+            if (std::fabs(wi) <= threshold) continue;
+            wi = 1 / wi;
+            double buffer[N];
+            for (int j = 0; j < N; j++) buffer[j] = 0;
+            for (int r = 0; r < N; r++) {
+                const float s = At[i][r];
+                for (int j = 0; j < N; j++) buffer[j] = buffer[j] + (double)(s * B[r * N + j]);
+            }
+            for (int j = 0; j < N; j++) buffer[j] *= wi;
+            for (int r = 0; r < N; r++) {
+                const float s = Vt[i][r];
+                for (int j = 0; j < N; j++) X[r * N + j] = (float)(X[r * N + j] + s * buffer[j]);
+            }
+        }
+    }
+    void predict() {
+        float temp1[N * N];
+        gemm(A, statePost, false, 1, nullptr, 0, statePre, N, N, 1);
+        gemm(A, errorCovPost, false, 1, nullptr, 0, temp1, N, N, N);
+        gemm(temp1, A, true, 1, Q, 1, errorCovPre, N, N, N);
+        std::memcpy(statePost, statePre, sizeof(statePre));
+        std::memcpy(errorCovPost, errorCovPre, sizeof(errorCovPre));
+    }
+    void correct(const float* z) {
+        float temp2[N * N], temp3[N * N], temp4[N * N], temp5[N], hx[N];
+        gemm(Hm, errorCovPre, false, 1, nullptr, 0, temp2, N, N, N);
+        gemm(temp2, Hm, true, 1, R, 1, temp3, N, N, N);
+        solve_svd(temp3, temp2, temp4);
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) gain[i * N + j] = temp4[j * N + i];
+        gemm(Hm, statePre, false, 1, nullptr, 0, hx, N, N, 1);
+        for (int i = 0; i < N; i++) temp5[i] = z[i] - hx[i];
+        gemm(gain, temp5, false, 1, statePre, 1, statePost, N, N, 1);
+        gemm(gain, temp2, false, -1, errorCovPre, 1, errorCovPost, N, N, N);
+    }
+    // StereoSlam::update_pose
+    void update(const float pose[6], const float speed[6], const float pv[6], const float sv[6],
+                double dt, float filtered[6]) {
+        for (int i = 0; i < 6; i++) A[i * N + 6 + i] = (float)dt;
+        predict();
+        for (int i = 0; i < 6; i++) { R[i * N + i] = pv[i]; R[(6 + i) * N + 6 + i] = sv[i]; }
+        float z[N];
+        for (int i = 0; i < 6; i++) { z[i] = pose[i]; z[6 + i] = speed[i]; }
+        correct(z);
+        for (int i = 0; i < 6; i++) filtered[i] = statePost[i];
+    }
+};
+
+struct ImageSet {
+    uint8_t* base = nullptr;
+    ImgView left[SVO_MAX_PYRAMID_LEVELS];
+    ImgView right;
+    ImgView lk[SVO_LK_LEVELS];
+    int refs = 0;
+};
+
+struct FrameResult {            // device -> host, one per sequence and frame
+    float pose_sia[6];
+    float pose_refined[6];
+    float sia_cost, reproj_cost;
+    int inside, overflow, kf_n, old_count;
+    svo_gn_trace sia_trace[SVO_MAX_PYRAMID_LEVELS];
+    svo_gn_trace reproj_trace;
+};
+
+struct KfHost {
+    ImageSet* set;
+    float pose[6];
+    int n;
+    svo_kp2d* kps2d; svo_kp3d* kps3d; uint32_t* flags; int* outl; int* inl;   // device
+};
+
+struct Seq {
+    KpsDev kps[2];
+    int cur = 0;
+    int* d_n = nullptr;          // [2] keypoint counts of the two sets
+    svo_kp2d* tracked = nullptr;
+    float* klt_err = nullptr;
+    uint8_t* klt_status = nullptr;
+    float* disparity = nullptr;
+    float4* sia_cache = nullptr;
+    float* sia_kpws = nullptr;
+    KfDev* d_kfs = nullptr;
+    std::vector<KfHost> kfs;
+    DetCell* det = nullptr; int* n_det = nullptr;
+    DetCell* sel = nullptr; int* sel_level = nullptr; int* sel_cell = nullptr; int* occupied = nullptr;
+    uint32_t* color_lcg = nullptr;
+    std::vector<ImageSet*> free_sets;
+    ImageSet* cur_set = nullptr;
+    ImageSet* prev_set = nullptr;
+    // host state
+    PoseFilter kf;
+    int frame_id = -1;
+    double ts = 0;
+    float pose[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<svo_pose> trajectory;
+    svo_frame_stats stats;
+    int n_host = 0;
+};
+
+}  // namespace
+
+struct svo_ctx {
+    int device, B, width, height, cap, max_kf, n_lk, det_levels, max_cells, merge_cells;
+    svo_camera_settings cam;
+    hipStream_t stream;
+    std::vector<Seq> seqs;
+    // argument blocks: pinned host mirror + device copy, one array per kernel
+    uint8_t* h_args = nullptr; uint8_t* d_args = nullptr; size_t args_bytes = 0;
+    size_t off_hs, off_lk, off_compact, off_sia, off_klt, off_rp, off_ssd, off_filt, off_det,
+        off_merge, off_init, off_guess, off_enable, off_kfdev;
+    FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;
+    int* h_n = nullptr;          // pinned [B*2]
+    int* d_n_all = nullptr;      // [B*2]
+    size_t sia_lds = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t set_bytes = 0;
+    std::vector<void*> allocs;   // everything to free
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(svo_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1)));
+    HIP_TRY(hipMemset(q, 0, sizeof(T) * std::max<size_t>(count, 1)));
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return SVO_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int new_image_set(svo_ctx* c, ImageSet** out) {
+    ImageSet* s = new ImageSet();
+    size_t off = 0;
+    size_t offs_left[SVO_MAX_PYRAMID_LEVELS], offs_lk[SVO_LK_LEVELS], off_right;
+    int w = c->width, h = c->height;
+    for (int l = 0; l < c->cam.max_pyramid_levels; l++) {
+        const int stride = (int)align_up((size_t)std::max(w, 1), 64);
+        offs_left[l] = off;
+        s->left[l] = ImgView{nullptr, w, h, stride};
+        off += align_up((size_t)stride * std::max(h, 1), 256);
+        w /= 2; h /= 2;
+    }
+    {
+        const int stride = (int)align_up((size_t)c->width, 64);
+        off_right = off;
+        s->right = ImgView{nullptr, c->width, c->height, stride};
+        off += align_up((size_t)stride * c->height, 256);
+    }
+    w = c->width; h = c->height;
+    for (int l = 1; l < c->n_lk; l++) {
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        const int stride = (int)align_up((size_t)w, 64);
+        offs_lk[l] = off;
+        s->lk[l] = ImgView{nullptr, w, h, stride};
+        off += align_up((size_t)stride * h, 256);
+    }
+    void* base = nullptr;
+    HIP_TRY(hipMalloc(&base, off));
+    c->allocs.push_back(base);
+    s->base = reinterpret_cast<uint8_t*>(base);
+    for (int l = 0; l < c->cam.max_pyramid_levels; l++) s->left[l].data = s->base + offs_left[l];
+    s->right.data = s->base + off_right;
+    s->lk[0] = s->left[0];
+    for (int l = 1; l < c->n_lk; l++) s->lk[l].data = s->base + offs_lk[l];
+    c->set_bytes = off;
+    *out = s;
+    return SVO_OK;
+}
+
+int acquire_set(svo_ctx* c, Seq& q, ImageSet** out) {
+    if (q.free_sets.empty()) {
+        ImageSet* s;
+        int rc = new_image_set(c, &s);
+        if (rc) return rc;
+        q.free_sets.push_back(s);
+    }
+    *out = q.free_sets.back();
+    q.free_sets.pop_back();
+    (*out)->refs = 1;
+    return SVO_OK;
+}
+
+void release_set(Seq& q, ImageSet* s) {
+    if (!s) return;
+    if (--s->refs <= 0) q.free_sets.push_back(s);
+}
+
+int alloc_kps(svo_ctx* c, KpsDev& k, int* n_ptr) {
+    const size_t cap = c->cap;
+    int rc;
+    if ((rc = dev_alloc(c, &k.kps2d, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.kps3d, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.flags, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.kf_id, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.kp_index, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.outl, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.inl, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.kfx, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.kfP, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.score, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.level_type, cap))) return rc;
+    if ((rc = dev_alloc(c, &k.color, cap))) return rc;
+    k.n = n_ptr;
+    return SVO_OK;
+}
+
+template <typename T>
+T* args_at(svo_ctx* c, size_t off, int s) { return reinterpret_cast<T*>(c->h_args + off) + s; }
+template <typename T>
+T* dargs_at(svo_ctx* c, size_t off, int s = 0) { return reinterpret_cast<T*>(c->d_args + off) + s; }
+
+int new_keyframe_storage(svo_ctx* c, Seq& q, int s, int id) {
+    if (id >= c->max_kf) return svo_set_error(SVO_ERR_CAPACITY, "more than %d keyframes", c->max_kf);
+    KfHost k;
+    std::memset(&k, 0, sizeof(k));
+    const size_t cap = c->cap;
+    const size_t bytes = cap * (sizeof(svo_kp2d) + sizeof(svo_kp3d) + 3 * sizeof(int));
+    uint8_t* base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
+    c->allocs.push_back(base);
+    k.kps3d = reinterpret_cast<svo_kp3d*>(base);
+    k.kps2d = reinterpret_cast<svo_kp2d*>(base + cap * sizeof(svo_kp3d));
+    k.flags = reinterpret_cast<uint32_t*>(base + cap * (sizeof(svo_kp3d) + sizeof(svo_kp2d)));
+    k.outl = reinterpret_cast<int*>(k.flags + cap);
+    k.inl = k.outl + cap;
+    k.set = q.cur_set;
+    q.cur_set->refs++;
+    q.kfs.push_back(k);
+    KfDev& d = *args_at<KfDev>(c, c->off_kfdev, s);   // pinned staging, stable until the frame ends
+    std::memset(&d, 0, sizeof(d));
+    for (int l = 0; l < c->n_lk; l++) d.lk[l] = q.cur_set->lk[l];
+    d.n_lk = c->n_lk;
+    d.kps2d = k.kps2d; d.kps3d = k.kps3d; d.flags = k.flags; d.outlier_count = k.outl; d.inlier_count = k.inl;
+    HIP_TRY(hipMemcpyAsync(q.d_kfs + id, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    return SVO_OK;
+}
+
+}  // namespace
+
+extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
+                              int device, svo_ctx** out) {
+    if (!cam || !out || width < 16 || height < 16 || n_sequences < 1)
+        return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
+    if (cam->max_pyramid_levels < 1 || cam->max_pyramid_levels > 7 ||
+        cam->min_pyramid_level_pose_estimation < 0 ||
+        cam->min_pyramid_level_pose_estimation >= cam->max_pyramid_levels)
+        return svo_set_error(SVO_ERR_INVALID, "max_pyramid_levels must be 1..7 and > min level");
+    if (cam->window_size_opt_flow < 3 || cam->window_size_opt_flow > 35 ||
+        cam->window_size_depth_calculator < 1 || cam->window_size_depth_calculator > 35 ||
+        cam->search_x < 0 || cam->search_x > 64 || cam->search_y < 0 || cam->search_y > 8)
+        return svo_set_error(SVO_ERR_INVALID, "windows <= 35, search_x <= 64, search_y <= 8 supported");
+    if (cam->grid_width < 4 || cam->grid_height < 4 || cam->grid_width > 96 || cam->grid_height > 64)
+        return svo_set_error(SVO_ERR_INVALID, "grid cell must be within 4..96 x 4..64");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return svo_set_error(SVO_ERR_NO_DEVICE, "no HIP device visible: libsvo_hip has no CPU fallback");
+    if (device < 0 || device >= count) return svo_set_error(SVO_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    svo_ctx* c = new (std::nothrow) svo_ctx();
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "out of host memory");
+    c->device = device; c->B = n_sequences; c->width = width; c->height = height; c->cam = *cam;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int cells = (width / cam->grid_width) * (height / cam->grid_height);
+    c->cap = (int)align_up((size_t)(2 * cells + 128), 64);
+    c->max_kf = 4096;
+    // usable LK levels (cv::buildOpticalFlowPyramid stops at levels not larger than the window)
+    {
+        int n = SVO_LK_LEVELS, w = width, h = height;
+        for (int l = 0; l < SVO_LK_LEVELS; l++) {
+            w = (w + 1) / 2; h = (h + 1) / 2;
+            if (w <= cam->window_size_opt_flow || h <= cam->window_size_opt_flow) { n = l + 1; break; }
+        }
+        c->n_lk = n;
+    }
+    c->det_levels = cam->max_pyramid_levels / 2;
+    c->max_cells = 1;
+    for (int l = 0; l < c->det_levels; l++) {
+        const int gw = cam->grid_width >> l, gh = cam->grid_height >> l;
+        if (gw <= 0 || gh <= 0) { c->det_levels = l; break; }
+        const int nc = ((width >> l) / gw) * std::max((height >> l) / gh, 1);
+        c->max_cells = std::max(c->max_cells, nc);
+    }
+    c->merge_cells = ((width + cam->grid_height - 1) / cam->grid_height) *
+                     ((height + cam->grid_width - 1) / cam->grid_width);
+    c->sia_lds = sia_lds_bytes(*cam, width, height, c->cap);
+
+    const int B = c->B;
+    // argument blocks
+    size_t off = 0;
+    auto reserve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    c->off_hs = reserve(sizeof(PyrArgs) * B);
+    c->off_lk = reserve(sizeof(PyrArgs) * B);
+    c->off_compact = reserve(sizeof(CompactArgs) * B);
+    c->off_sia = reserve(sizeof(SiaArgs) * B);
+    c->off_klt = reserve(sizeof(KltArgs) * B);
+    c->off_rp = reserve(sizeof(ReprojArgs) * B);
+    c->off_ssd = reserve(sizeof(SsdArgs) * B);
+    c->off_filt = reserve(sizeof(FilterArgs) * B);
+    c->off_det = reserve(sizeof(DetectArgs) * B);
+    c->off_merge = reserve(sizeof(MergeArgs) * B);
+    c->off_init = reserve(sizeof(KfInitArgs) * B);
+    c->off_guess = reserve(sizeof(float) * 8 * B);
+    c->off_enable = reserve(sizeof(int) * B);
+    c->off_kfdev = reserve(sizeof(KfDev) * B);
+    c->args_bytes = off;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_args), off, hipHostMallocDefault));
+    std::memset(c->h_args, 0, off);
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_args, off))) return rc;
+    if ((rc = dev_alloc(c, &c->d_res, (size_t)B))) return rc;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_res), sizeof(FrameResult) * B, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_n), sizeof(int) * 2 * B, hipHostMallocDefault));
+    if ((rc = dev_alloc(c, &c->d_n_all, (size_t)2 * B))) return rc;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+
+    c->seqs.resize(B);
+    for (int s = 0; s < B; s++) {
+        Seq& q = c->seqs[s];
+        q.d_n = c->d_n_all + 2 * s;
+        if ((rc = alloc_kps(c, q.kps[0], q.d_n))) return rc;
+        if ((rc = alloc_kps(c, q.kps[1], q.d_n + 1))) return rc;
+        if ((rc = dev_alloc(c, &q.tracked, (size_t)c->cap))) return rc;
+        if ((rc = dev_alloc(c, &q.klt_err, (size_t)c->cap))) return rc;
+        if ((rc = dev_alloc(c, &q.klt_status, (size_t)c->cap))) return rc;
+        if ((rc = dev_alloc(c, &q.disparity, (size_t)c->cap))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_cache, (size_t)c->cap * 16))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)c->cap * 8))) return rc;
+        if ((rc = dev_alloc(c, &q.d_kfs, (size_t)c->max_kf))) return rc;
+        if ((rc = dev_alloc(c, &q.det, (size_t)SVO_MAX_PYRAMID_LEVELS * c->max_cells))) return rc;
+        if ((rc = dev_alloc(c, &q.n_det, (size_t)SVO_MAX_PYRAMID_LEVELS))) return rc;
+        if ((rc = dev_alloc(c, &q.sel, (size_t)c->max_cells))) return rc;
+        if ((rc = dev_alloc(c, &q.sel_level, (size_t)c->max_cells))) return rc;
+        if ((rc = dev_alloc(c, &q.sel_cell, (size_t)c->max_cells))) return rc;
+        if ((rc = dev_alloc(c, &q.occupied, (size_t)c->merge_cells))) return rc;
+        if ((rc = dev_alloc(c, &q.color_lcg, (size_t)1))) return rc;
+        const uint32_t lcg = 12345u;
+        HIP_TRY(hipMemcpy(q.color_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
+        q.kf.init();
+        std::memset(&q.stats, 0, sizeof(q.stats));
+        for (int i = 0; i < 4; i++) {       // pre-allocate a few image sets
+            ImageSet* is;
+            if ((rc = new_image_set(c, &is))) return rc;
+            q.free_sets.push_back(is);
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = c;
+    return SVO_OK;
+}
+
+extern "C" int svo_ctx_destroy(svo_ctx* c) {
+    if (!c) return SVO_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_args) (void)hipHostFree(c->h_args);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_n) (void)hipHostFree(c->h_n);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    // ImageSet structs: owned by the free lists, the current/previous pointers and keyframes
+    for (Seq& q : c->seqs) {
+        std::vector<ImageSet*> all(q.free_sets);
+        if (q.cur_set) all.push_back(q.cur_set);
+        if (q.prev_set) all.push_back(q.prev_set);
+        for (auto& k : q.kfs) all.push_back(k.set);
+        std::sort(all.begin(), all.end());
+        all.erase(std::unique(all.begin(), all.end()), all.end());
+        for (ImageSet* s : all) delete s;
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SVO_OK;
+}
+
+extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "null ctx");
+    c->timing = on != 0;
+    return SVO_OK;
+}
+
+// keyframe creation for the sequences whose enable flag is set (device predicate)
+static int enqueue_keyframes(svo_ctx* c, const std::vector<int>& need, bool first_frame) {
+    const int B = c->B;
+    for (int s = 0; s < B; s++) {
+        Seq& q = c->seqs[s];
+        *args_at<int>(c, c->off_enable, s) = need[s];
+        const int* d_en = dargs_at<int>(c, c->off_enable, s);
+        if (!need[s]) {
+            args_at<CompactArgs>(c, c->off_compact, s)->enable = d_en;
+            args_at<DetectArgs>(c, c->off_det, s)->enable = d_en;
+            args_at<MergeArgs>(c, c->off_merge, s)->enable = d_en;
+            args_at<SsdArgs>(c, c->off_ssd, s)->enable = d_en;
+            args_at<KfInitArgs>(c, c->off_init, s)->enable = d_en;
+            continue;
+        }
+        const int id = (int)q.kfs.size();
+        int rc = new_keyframe_storage(c, q, s, id);
+        if (rc) return rc;
+        // find_bad_keypoints: cur -> other, then the other set is current
+        CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, s);
+        ca->src = q.kps[q.cur]; ca->dst = q.kps[q.cur ^ 1]; ca->mode = 1;
+        ca->width = c->width; ca->height = c->height; ca->enable = d_en;
+        q.cur ^= 1;
+        DetectArgs* da = args_at<DetectArgs>(c, c->off_det, s);
+        std::memset(da, 0, sizeof(*da));
+        for (int l = 0; l < c->cam.max_pyramid_levels; l++) da->level[l] = q.cur_set->left[l];
+        da->n_levels = c->det_levels; da->grid_w = c->cam.grid_width; da->grid_h = c->cam.grid_height;
+        da->out = q.det; da->n_out = q.n_det; da->max_cells = c->max_cells; da->enable = d_en;
+        MergeArgs* ma = args_at<MergeArgs>(c, c->off_merge, s);
+        std::memset(ma, 0, sizeof(*ma));
+        ma->cam = c->cam; ma->width = c->width; ma->height = c->height;
+        ma->det = q.det; ma->n_det = q.n_det; ma->n_levels = c->det_levels; ma->max_cells = c->max_cells;
+        ma->kps = q.kps[q.cur]; ma->cap = c->cap;
+        ma->sel = q.sel; ma->sel_level = q.sel_level; ma->sel_cell = q.sel_cell; ma->occupied = q.occupied;
+        ma->old_count = &c->d_res[s].old_count; ma->overflow = &c->d_res[s].overflow; ma->enable = d_en;
+        SsdArgs* sa = args_at<SsdArgs>(c, c->off_ssd, s);
+        std::memset(sa, 0, sizeof(*sa));
+        sa->left = q.cur_set->left[0]; sa->right = q.cur_set->right;
+        sa->n_ptr = q.kps[q.cur].n; sa->kps2d = q.kps[q.cur].kps2d; sa->disparity = q.disparity;
+        sa->win = c->cam.window_size_depth_calculator; sa->search_x = c->cam.search_x;
+        sa->search_y = c->cam.search_y; sa->clamp_half = 0;
+        sa->first = 0; sa->first_ptr = &c->d_res[s].old_count; sa->enable = d_en;
+        KfInitArgs* ia = args_at<KfInitArgs>(c, c->off_init, s);
+        std::memset(ia, 0, sizeof(*ia));
+        ia->cam = c->cam; ia->kps = q.kps[q.cur]; ia->old_count = &c->d_res[s].old_count;
+        ia->disparity = q.disparity; ia->frame_pose = c->d_res[s].pose_refined;
+        ia->first_frame = first_frame ? 1 : 0; ia->new_kf_id = id; ia->kfs = q.d_kfs;
+        ia->color_lcg = q.color_lcg; ia->n_out = &c->d_res[s].kf_n; ia->enable = d_en;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
+    for (int s = 0; s < B; s++)
+        if (need[s]) HIP_TRY(hipMemsetAsync(c->seqs[s].n_det, 0, sizeof(int) * SVO_MAX_PYRAMID_LEVELS, c->stream));
+    launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
+    if (c->det_levels > 0)
+        launch_detect(dargs_at<DetectArgs>(c, c->off_det), B, c->max_cells, c->det_levels, c->stream);
+    launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), B, c->stream);
+    launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, c->cap, c->stream);
+    launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), B, c->stream);
+    HIP_TRY(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint8_t* const* right,
+                              int stride, const float* time_stamps, int mem) {
+    if (!c || !left || !right || !time_stamps || stride < c->width)
+        return svo_set_error(SVO_ERR_INVALID, "svo_new_images: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = c->B;
+    const hipMemcpyKind kind = mem == SVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const bool first = c->seqs[0].frame_id < 0;
+    int rc;
+
+    // ---- images in, pyramids
+    for (int s = 0; s < B; s++) {
+        Seq& q = c->seqs[s];
+        release_set(q, q.prev_set);
+        q.prev_set = q.cur_set;
+        if ((rc = acquire_set(c, q, &q.cur_set))) return rc;
+        ImageSet* is = q.cur_set;
+        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->left[0].data), is->left[0].stride, left[s],
+                                 stride, c->width, c->height, kind, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->right.data), is->right.stride, right[s],
+                                 stride, c->width, c->height, kind, c->stream));
+        PyrArgs* hs = args_at<PyrArgs>(c, c->off_hs, s);
+        std::memset(hs, 0, sizeof(*hs));
+        hs->n_levels = c->cam.max_pyramid_levels;
+        for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
+        PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, s);
+        std::memset(lk, 0, sizeof(*lk));
+        lk->n_levels = c->n_lk;
+        for (int l = 0; l < c->n_lk; l++) lk->level[l] = is->lk[l];
+    }
+
+    if (!first) {
+        for (int s = 0; s < B; s++) {
+            Seq& q = c->seqs[s];
+            FrameResult* dr = c->d_res + s;
+            // predicted pose = kf.statePre (stereo_slam.cpp:183-192)
+            float* guess = args_at<float>(c, c->off_guess, s * 8);
+            for (int i = 0; i < 6; i++) guess[i] = q.kf.statePre[i];
+            const float* d_guess = dargs_at<float>(c, c->off_guess, s * 8);
+            // remove_outliers: previous set -> other set (becomes the frame's keypoints)
+            CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, s);
+            std::memset(ca, 0, sizeof(*ca));
+            ca->src = q.kps[q.cur]; ca->dst = q.kps[q.cur ^ 1]; ca->mode = 0;
+            q.cur ^= 1;
+            const KpsDev& k = q.kps[q.cur];
+            SiaArgs* sa = args_at<SiaArgs>(c, c->off_sia, s);
+            std::memset(sa, 0, sizeof(*sa));
+            for (int l = 0; l < c->cam.max_pyramid_levels; l++) {
+                sa->prev[l] = q.prev_set->left[l];
+                sa->cur[l] = q.cur_set->left[l];
+            }
+            sa->cam = c->cam; sa->n_ptr = k.n; sa->kps2d = k.kps2d; sa->kps3d = k.kps3d; sa->flags = k.flags;
+            sa->pose_guess = d_guess; sa->pose_out = dr->pose_sia; sa->cost_out = &dr->sia_cost;
+            sa->trace = dr->sia_trace; sa->cache = q.sia_cache; sa->kp_ws = q.sia_kpws;
+            sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap;
+            KltArgs* ka = args_at<KltArgs>(c, c->off_klt, s);
+            std::memset(ka, 0, sizeof(*ka));
+            ka->kfs = q.d_kfs; ka->kf_id = k.kf_id; ka->n_cur = c->n_lk;
+            for (int l = 0; l < c->n_lk; l++) ka->cur[l] = q.cur_set->lk[l];
+            ka->n_ptr = k.n; ka->prev_pts = nullptr; ka->cur_pts = q.tracked; ka->status = q.klt_status;
+            ka->err = q.klt_err; ka->win = c->cam.window_size_opt_flow;
+            ka->proj_pose = dr->pose_sia; ka->kps3d = k.kps3d; ka->proj_out = k.kps2d;
+            ka->kp_index = k.kp_index; ka->ref_out = nullptr; ka->cam = c->cam;
+            ReprojArgs* ra = args_at<ReprojArgs>(c, c->off_rp, s);
+            std::memset(ra, 0, sizeof(*ra));
+            ra->cam = c->cam; ra->n_ptr = k.n; ra->kps2d = k.kps2d; ra->kps3d = k.kps3d; ra->flags = k.flags;
+            ra->tracked = q.tracked; ra->err = q.klt_err; ra->pose_in = dr->pose_sia;
+            ra->pose_out = dr->pose_refined; ra->cost_out = &dr->reproj_cost; ra->trace = &dr->reproj_trace;
+            SsdArgs* ss = args_at<SsdArgs>(c, c->off_ssd, s);
+            std::memset(ss, 0, sizeof(*ss));
+            ss->left = q.cur_set->left[0]; ss->right = q.cur_set->right; ss->n_ptr = k.n;
+            ss->kps2d = k.kps2d; ss->disparity = q.disparity;
+            ss->win = c->cam.window_size_depth_calculator; ss->search_x = c->cam.search_x;
+            ss->search_y = c->cam.search_y; ss->clamp_half = 1;
+            FilterArgs* fa = args_at<FilterArgs>(c, c->off_filt, s);
+            std::memset(fa, 0, sizeof(*fa));
+            fa->cam = c->cam; fa->n_ptr = k.n; fa->frame_pose = dr->pose_refined;
+            fa->kps2d = k.kps2d; fa->kps3d = k.kps3d; fa->flags = k.flags;
+            fa->outlier_count = k.outl; fa->inlier_count = k.inl; fa->kf_inv_depth = k.kfx;
+            fa->kf_variance = k.kfP; fa->disparity = q.disparity;
+            fa->kfs = q.d_kfs; fa->kf_id = k.kf_id; fa->kp_index = k.kp_index;
+            fa->do_outlier_check = 1; fa->do_update = 1; fa->do_flags = 1; fa->do_reproject = 1;
+            fa->width = c->width; fa->height = c->height; fa->inside_count = &dr->inside;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
+    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height, c->stream);
+    {
+        int w = c->width, h = c->height;
+        for (int l = 0; l + 1 < c->n_lk; l++) {
+            w = (w + 1) / 2; h = (h + 1) / 2;
+            launch_pyr_down(dargs_at<PyrArgs>(c, c->off_lk), B, l, w, h, c->stream);
+        }
+    }
+    std::vector<int> need(B, 0);
+    if (first) {
+        for (int s = 0; s < B; s++) {
+            need[s] = 1;
+            HIP_TRY(hipMemsetAsync(c->seqs[s].d_n, 0, sizeof(int) * 2, c->stream));
+        }
+        HIP_TRY(hipMemsetAsync(c->d_res, 0, sizeof(FrameResult) * B, c->stream));
+        if ((rc = enqueue_keyframes(c, need, true))) return rc;
+    } else {
+        launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->sia_lds, c->cap, c->stream);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, c->cap, c->cam.window_size_opt_flow, c->stream);
+        launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), B, c->stream);
+        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, c->cap, c->stream);
+        launch_filter(dargs_at<FilterArgs>(c, c->off_filt), B, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        // KeyFrameManager::keyframe_needed (keyframe_manager.cpp:66-72)
+        const int max_keypoints = (c->width / c->cam.grid_width) * (c->height / c->cam.grid_height);
+        bool any = false;
+        for (int s = 0; s < B; s++) {
+            need[s] = (double)c->h_res[s].inside < 0.66 * max_keypoints ? 1 : 0;
+            any = any || need[s];
+        }
+        if (any && (rc = enqueue_keyframes(c, need, false))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_n, c->d_n_all, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    float sia_ms = 0;
+    if (c->timing && !first) (void)hipEventElapsedTime(&sia_ms, c->ev0, c->ev1);
+
+    // ---- host bookkeeping: pose filter, trajectory (stereo_slam.cpp:250-270)
+    for (int s = 0; s < B; s++) {
+        Seq& q = c->seqs[s];
+        const FrameResult& r = c->h_res[s];
+        const double ts = (double)time_stamps[s];
+        float prev_pose[6];
+        std::memcpy(prev_pose, q.pose, sizeof(prev_pose));
+        q.frame_id++;
+        if (first) {
+            std::memset(q.pose, 0, sizeof(q.pose));
+        } else {
+            std::memcpy(q.pose, r.pose_refined, sizeof(q.pose));
+            const double dt = ts - q.ts;
+            const double inv = 1. / dt;
+            float motion[6];
+            for (int i = 0; i < 6; i++) motion[i] = (float)((q.pose[i] - prev_pose[i]) * inv);
+            const float pv[6] = {0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f};
+            const float mv[6] = {1, 1, 1, 1, 1, 1};
+            float filtered[6];
+            q.kf.update(q.pose, motion, pv, mv, 0.0, filtered);
+            std::memcpy(q.pose, filtered, sizeof(q.pose));
+        }
+        q.ts = ts;
+        if (need[s]) {
+            KfHost& k = q.kfs.back();
+            k.n = r.kf_n;
+            std::memcpy(k.pose, first ? q.pose : r.pose_refined, sizeof(k.pose));
+        }
+        q.n_host = c->h_n[2 * s + q.cur];
+        svo_pose p;
+        std::memcpy(&p, q.pose, sizeof(p));
+        q.trajectory.push_back(p);
+        svo_frame_stats& st = q.stats;
+        std::memset(&st, 0, sizeof(st));
+        st.frame_id = q.frame_id; st.is_keyframe = need[s]; st.n_keypoints = q.n_host;
+        st.n_keyframes = (int)q.kfs.size(); st.inside_count = r.inside; st.overflow = r.overflow;
+        std::memcpy(st.pose_sia, r.pose_sia, sizeof(st.pose_sia));
+        std::memcpy(st.pose_refined, r.pose_refined, sizeof(st.pose_refined));
+        st.sia_cost = r.sia_cost; st.reproj_cost = r.reproj_cost; st.sia_ms = sia_ms;
+        std::memcpy(st.sia_trace, r.sia_trace, sizeof(st.sia_trace));
+        st.reproj_trace = r.reproj_trace;
+        if (r.overflow) return svo_set_error(SVO_ERR_CAPACITY, "sequence %d: more than %d keypoints", s, c->cap);
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, const uint8_t* right,
+                             int right_stride, int width, int height, float time_stamp) {
+    if (!c || c->B != 1) return svo_set_error(SVO_ERR_INVALID, "svo_new_image needs a 1-sequence ctx");
+    if (width != c->width || height != c->height || left_stride != right_stride)
+        return svo_set_error(SVO_ERR_INVALID, "svo_new_image: image size / stride mismatch");
+    return svo_new_images(c, &left, &right, left_stride, &time_stamp, SVO_MEM_HOST);
+}
+
+#define CHECK_SEQ(c, seq)                                                              \
+    do {                                                                               \
+        if (!(c) || (seq) < 0 || (seq) >= (c)->B)                                      \
+            return svo_set_error(SVO_ERR_INVALID, "bad ctx / sequence index");         \
+        HIP_TRY(hipSetDevice((c)->device));                                            \
+    } while (0)
+
+extern "C" int svo_get_pose(svo_ctx* c, int seq, float pose[6]) {
+    CHECK_SEQ(c, seq);
+    std::memcpy(pose, c->seqs[seq].pose, sizeof(float) * 6);
+    return SVO_OK;
+}
+
+static int fetch_info(svo_ctx* c, int n, const svo_kp2d* d2, const svo_kp3d* d3, const uint32_t* dfl,
+                      const int* dkf, const int* dki, const int* dout, const int* din, const float* dkx,
+                      const float* dkP, const float* dsc, const int* dlt, const uint32_t* dcol,
+                      svo_kp2d* kps2d, svo_kp3d* kps3d, svo_kp_info* info) {
+    if (n <= 0) return SVO_OK;
+    if (kps2d) HIP_TRY(hipMemcpy(kps2d, d2, sizeof(svo_kp2d) * n, hipMemcpyDeviceToHost));
+    if (kps3d) HIP_TRY(hipMemcpy(kps3d, d3, sizeof(svo_kp3d) * n, hipMemcpyDeviceToHost));
+    if (!info) return SVO_OK;
+    std::vector<uint32_t> fl(n), col(n, 0);
+    std::vector<int> kf(n, 0), ki(n, 0), ou(n), in(n), lt(n, 0);
+    std::vector<float> kx(n, 0), kP(n, 0), sc(n, 0);
+    HIP_TRY(hipMemcpy(fl.data(), dfl, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ou.data(), dout, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(in.data(), din, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (dkf) HIP_TRY(hipMemcpy(kf.data(), dkf, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (dki) HIP_TRY(hipMemcpy(ki.data(), dki, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (dkx) HIP_TRY(hipMemcpy(kx.data(), dkx, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (dkP) HIP_TRY(hipMemcpy(kP.data(), dkP, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (dsc) HIP_TRY(hipMemcpy(sc.data(), dsc, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (dlt) HIP_TRY(hipMemcpy(lt.data(), dlt, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (dcol) HIP_TRY(hipMemcpy(col.data(), dcol, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        svo_kp_info& o = info[i];
+        std::memset(&o, 0, sizeof(o));
+        o.score = sc[i]; o.level = lt[i] & 0xff; o.type = (lt[i] >> 8) & 0xff;
+        o.keyframe_id = kf[i]; o.keypoint_index = ki[i];
+        o.color[0] = col[i] & 0xff; o.color[1] = (col[i] >> 8) & 0xff; o.color[2] = (col[i] >> 16) & 0xff;
+        o.ignore_during_refinement = (fl[i] & SVO_IGNORE_DURING_REFINEMENT) != 0;
+        o.ignore_completely = (fl[i] & SVO_IGNORE_COMPLETELY) != 0;
+        o.ignore_temporary = (fl[i] & SVO_IGNORE_TEMPORARY) != 0;
+        o.outlier_count = ou[i]; o.inlier_count = in[i];
+        o.kf_inv_depth = kx[i]; o.kf_variance = kP[i];
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_get_frame_keypoints(svo_ctx* c, int seq, svo_kp2d* kps2d, svo_kp3d* kps3d,
+                                       svo_kp_info* info, int cap, int* n) {
+    CHECK_SEQ(c, seq);
+    Seq& q = c->seqs[seq];
+    if (n) *n = q.n_host;
+    const KpsDev& k = q.kps[q.cur];
+    return fetch_info(c, std::min(cap, q.n_host), k.kps2d, k.kps3d, k.flags, k.kf_id, k.kp_index,
+                      k.outl, k.inl, k.kfx, k.kfP, k.score, k.level_type, k.color, kps2d, kps3d, info);
+}
+
+extern "C" int svo_get_keyframe_count(svo_ctx* c, int seq, int* count) {
+    CHECK_SEQ(c, seq);
+    if (count) *count = (int)c->seqs[seq].kfs.size();
+    return SVO_OK;
+}
+
+extern "C" int svo_get_keyframe(svo_ctx* c, int seq, int id, svo_kp2d* kps2d, svo_kp3d* kps3d,
+                                svo_kp_info* info, float pose[6], int cap, int* n) {
+    CHECK_SEQ(c, seq);
+    Seq& q = c->seqs[seq];
+    if (id < 0 || id >= (int)q.kfs.size()) return svo_set_error(SVO_ERR_INVALID, "keyframe %d does not exist", id);
+    const KfHost& k = q.kfs[id];
+    if (n) *n = k.n;
+    if (pose) std::memcpy(pose, k.pose, sizeof(float) * 6);
+    return fetch_info(c, std::min(cap, k.n), k.kps2d, k.kps3d, k.flags, nullptr, nullptr, k.outl, k.inl,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, kps2d, kps3d, info);
+}
+
+extern "C" int svo_get_trajectory(svo_ctx* c, int seq, svo_pose* out, int cap, int* n) {
+    CHECK_SEQ(c, seq);
+    Seq& q = c->seqs[seq];
+    if (n) *n = (int)q.trajectory.size();
+    const int m = std::min<int>(cap, (int)q.trajectory.size());
+    if (out && m > 0) std::memcpy(out, q.trajectory.data(), sizeof(svo_pose) * m);
+    return SVO_OK;
+}
+
+extern "C" int svo_update_pose(svo_ctx* c, int seq, const float pose[6], const float speed[6],
+                               const float pose_var[6], const float speed_var[6], double dt,
+                               float filtered[6]) {
+    CHECK_SEQ(c, seq);
+    c->seqs[seq].kf.update(pose, speed, pose_var, speed_var, dt, filtered);
+    return SVO_OK;
+}
+
+extern "C" int svo_get_frame_stats(svo_ctx* c, int seq, svo_frame_stats* out) {
+    CHECK_SEQ(c, seq);
+    if (out) *out = c->seqs[seq].stats;
+    return SVO_OK;
+}

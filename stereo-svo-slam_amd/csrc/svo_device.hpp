@@ -177,7 +177,7 @@ __device__ inline void exponential_map(const float twist[6], float out[6]) {
 // Matx66f::inv(DECOMP_SVD) (pose_estimator.cpp:405, pose_refinement.cpp:398),
 // cv::solve(DECOMP_SVD) (depth_filter.cpp:200) and cv::KalmanFilter::correct.
 template <int M, int N>
-__device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], float (&Vt)[N][N]) {
+__host__ __device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], float (&Vt)[N][N]) {
     const float eps = FLT_EPSILON * 2;
     double Wd[N];
     for (int i = 0; i < N; i++) {

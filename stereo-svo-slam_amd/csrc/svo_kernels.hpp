@@ -100,6 +100,8 @@ struct SsdArgs {
     float* disparity;
     int win, search_x, search_y, clamp_half;
     int first;                    // process kps [first, n)
+    const int* first_ptr;         // optional device value added to `first`
+    const int* enable;            // optional device predicate
 };
 void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream);
 

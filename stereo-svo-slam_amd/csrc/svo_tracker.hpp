@@ -1,0 +1,85 @@
+// svo_tracker.hpp — device-side data layout of one tracked sequence and the
+// argument blocks of the bookkeeping / keyframe kernels (keyframe.hip).
+#pragma once
+
+#include "svo_kernels.hpp"
+
+namespace svo {
+
+// Struct-of-arrays keypoint set in HBM (KeyPoints, src/include/stereo_slam_types.hpp:106-110;
+// KeyPointInformation :85-98 split by field so that every kernel streams only
+// the arrays it touches).
+struct KpsDev {
+    svo_kp2d* kps2d;
+    svo_kp3d* kps3d;
+    uint32_t* flags;
+    int* kf_id;
+    int* kp_index;
+    int* outl;
+    int* inl;
+    float* kfx;        // depth filter state 1/z
+    float* kfP;        // depth filter variance
+    float* score;
+    int* level_type;   // level | type << 8
+    uint32_t* color;
+    int* n;
+};
+
+struct CompactArgs {
+    KpsDev src, dst;
+    int mode;          // 0: remove_outliers, 1: find_bad_keypoints
+    int width, height;
+    const int* enable; // optional device predicate
+};
+void launch_compact(const CompactArgs* d_args, int batch, hipStream_t stream);
+
+struct DetCell {
+    float x, y, score;
+    int type;
+};
+
+struct DetectArgs {
+    ImgView level[SVO_MAX_PYRAMID_LEVELS];
+    int n_levels;      // left.size()/2
+    int grid_w, grid_h;
+    DetCell* out;      // [n_levels][max_cells]
+    int* n_out;        // [n_levels]
+    int max_cells;
+    const int* enable;
+};
+void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, hipStream_t stream);
+
+struct MergeArgs {
+    svo_camera_settings cam;
+    int width, height;
+    const DetCell* det;
+    const int* n_det;
+    int n_levels, max_cells;
+    KpsDev kps;
+    int cap;
+    DetCell* sel;      // [max_cells]
+    int* sel_level;    // [max_cells]
+    int* sel_cell;     // [max_cells]
+    int* occupied;     // [merge cells]
+    int* old_count;
+    int* overflow;
+    const int* enable;
+};
+void launch_select_merge(const MergeArgs* d_args, int batch, hipStream_t stream);
+
+struct KfInitArgs {
+    svo_camera_settings cam;
+    KpsDev kps;
+    const int* old_count;
+    const float* disparity;
+    const float* frame_pose;
+    int first_frame;
+    int new_kf_id;
+    KfDev* kfs;
+    uint32_t* color_lcg;
+    int* n_out;
+    const int* enable;
+};
+void launch_kf_init(const KfInitArgs* d_args, int batch, hipStream_t stream);
+
+}  // namespace svo

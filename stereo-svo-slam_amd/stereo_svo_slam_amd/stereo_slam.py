@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference's user API on top of the C ABI.
+
+`StereoSlam` has the live surface of the reference's Python wrapper
+(src/python/wrapper/slam_accelerator.pyx:50-91: ctor(CameraSettings),
+new_image(left, right, time_stamp), get_frame(), get_keyframe(), get_keyframes())
+and of the C++ class (src/include/stereo_slam.hpp:35-62: + get_trajectory,
+update_pose).  `StereoSlamBatch` drives B independent sequences through the same
+kernel launches (one svo_ctx).  No compute happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip_lib
+from .hip_lib import CameraSettings, SvoError, _check, lib
+
+KP_INFO_DTYPE = np.dtype([
+    ("score", "<f4"), ("level", "<i4"), ("type", "<i4"), ("keyframe_id", "<i4"),
+    ("keypoint_index", "<i4"), ("color", "u1", (3,)), ("ignore_during_refinement", "u1"),
+    ("ignore_completely", "u1"), ("ignore_temporary", "u1"), ("_pad", "u1", (2,)),
+    ("outlier_count", "<i4"), ("inlier_count", "<i4"), ("kf_inv_depth", "<f4"),
+    ("kf_variance", "<f4")], align=False)
+assert KP_INFO_DTYPE.itemsize == 44
+
+
+class GnTrace(C.Structure):
+    _fields_ = [("level", C.c_int32), ("n_gradient", C.c_int32), ("n_cost", C.c_int32),
+                ("n_accepted", C.c_int32), ("exit_small", C.c_int32),
+                ("initial_cost", C.c_float), ("final_cost", C.c_float), ("pose", C.c_float * 6)]
+
+
+class FrameStats(C.Structure):
+    """svo_frame_stats (include/svo_hip.h)."""
+    _fields_ = [("frame_id", C.c_int32), ("is_keyframe", C.c_int32), ("n_keypoints", C.c_int32),
+                ("n_keyframes", C.c_int32), ("inside_count", C.c_int32), ("overflow", C.c_int32),
+                ("pose_sia", C.c_float * 6), ("pose_refined", C.c_float * 6),
+                ("sia_cost", C.c_float), ("reproj_cost", C.c_float), ("sia_ms", C.c_float),
+                ("sia_trace", GnTrace * 8), ("reproj_trace", GnTrace)]
+
+
+class Frame:
+    """Frame / KeyFrame (src/include/stereo_slam_types.hpp:117-131) without images."""
+
+    def __init__(self, pose, kps2d, kps3d, info):
+        self.pose = pose
+        self.kps2d = kps2d
+        self.kps3d = kps3d
+        self.info = info
+
+
+class StereoSlamBatch:
+    def __init__(self, camera_settings, width, height, n_sequences=1, device=0):
+        if isinstance(camera_settings, dict):
+            camera_settings = CameraSettings.from_dict(camera_settings)
+        if not torch.cuda.is_available():
+            raise SvoError("no GPU visible: libsvo_hip has no CPU fallback")
+        self.cam = camera_settings
+        self.width, self.height, self.n = width, height, n_sequences
+        self.device = torch.device("cuda", device)
+        self._ctx = C.c_void_p()
+        _check(lib().svo_ctx_create(C.byref(self.cam), width, height, n_sequences, device,
+                                    C.byref(self._ctx)))
+
+    def close(self):
+        if getattr(self, "_ctx", None) and hip_lib._LIB is not None:
+            hip_lib._LIB.svo_ctx_destroy(self._ctx)
+        self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enable_timing(self, on=True):
+        _check(lib().svo_ctx_enable_timing(self._ctx, int(on)))
+
+    def new_images(self, lefts, rights, time_stamps):
+        """lefts/rights: per sequence a uint8 [H, W] numpy array (host) or torch CUDA tensor."""
+        assert len(lefts) == self.n and len(rights) == self.n
+        on_dev = isinstance(lefts[0], torch.Tensor)
+        ptrs_l = (C.c_void_p * self.n)()
+        ptrs_r = (C.c_void_p * self.n)()
+        keep = []
+        stride = None
+        for s in range(self.n):
+            for arr, dst in ((lefts[s], ptrs_l), (rights[s], ptrs_r)):
+                if on_dev:
+                    assert arr.is_cuda and arr.dtype == torch.uint8 and arr.stride(1) == 1
+                    st, p = arr.stride(0), arr.data_ptr()
+                else:
+                    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+                    st, p = arr.strides[0], arr.ctypes.data
+                assert tuple(arr.shape) == (self.height, self.width)
+                assert stride is None or stride == st
+                stride = st
+                keep.append(arr)
+                dst[s] = p
+        if on_dev:
+            torch.cuda.current_stream(self.device).synchronize()
+        ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
+        _check(lib().svo_new_images(self._ctx, ptrs_l, ptrs_r, stride, ts, 1 if on_dev else 0))
+
+    def pose(self, seq=0):
+        p = np.zeros(6, np.float32)
+        _check(lib().svo_get_pose(self._ctx, seq, p.ctypes.data_as(C.c_void_p)))
+        return p
+
+    def stats(self, seq=0):
+        st = FrameStats()
+        _check(lib().svo_get_frame_stats(self._ctx, seq, C.byref(st)))
+        return st
+
+    def get_frame(self, seq=0):
+        n = C.c_int(0)
+        _check(lib().svo_get_frame_keypoints(self._ctx, seq, None, None, None, 0, C.byref(n)))
+        k2 = np.zeros((n.value, 2), np.float32)
+        k3 = np.zeros((n.value, 3), np.float32)
+        info = np.zeros(n.value, KP_INFO_DTYPE)
+        _check(lib().svo_get_frame_keypoints(self._ctx, seq, k2.ctypes.data_as(C.c_void_p),
+                                             k3.ctypes.data_as(C.c_void_p),
+                                             info.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return Frame(self.pose(seq), k2, k3, info)
+
+    def num_keyframes(self, seq=0):
+        n = C.c_int(0)
+        _check(lib().svo_get_keyframe_count(self._ctx, seq, C.byref(n)))
+        return n.value
+
+    def get_keyframe(self, kid=None, seq=0):
+        if kid is None:
+            kid = self.num_keyframes(seq) - 1
+        n = C.c_int(0)
+        pose = np.zeros(6, np.float32)
+        _check(lib().svo_get_keyframe(self._ctx, seq, kid, None, None, None,
+                                      pose.ctypes.data_as(C.c_void_p), 0, C.byref(n)))
+        k2 = np.zeros((n.value, 2), np.float32)
+        k3 = np.zeros((n.value, 3), np.float32)
+        info = np.zeros(n.value, KP_INFO_DTYPE)
+        _check(lib().svo_get_keyframe(self._ctx, seq, kid, k2.ctypes.data_as(C.c_void_p),
+                                      k3.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p),
+                                      pose.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return Frame(pose, k2, k3, info)
+
+    def get_keyframes(self, seq=0):
+        return [self.get_keyframe(i, seq) for i in range(self.num_keyframes(seq))]
+
+    def get_trajectory(self, seq=0):
+        n = C.c_int(0)
+        _check(lib().svo_get_trajectory(self._ctx, seq, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 6), np.float32)
+        _check(lib().svo_get_trajectory(self._ctx, seq, out.ctypes.data_as(C.c_void_p), n.value,
+                                        C.byref(n)))
+        return out
+
+    def update_pose(self, pose, speed, pose_variance, speed_variance, dt, seq=0):
+        out = np.zeros(6, np.float32)
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (pose, speed, pose_variance, speed_variance)]
+        _check(lib().svo_update_pose(self._ctx, seq, *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                     C.c_double(dt), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class StereoSlam(StereoSlamBatch):
+    """One sequence: the reference's StereoSlam."""
+
+    def __init__(self, camera_settings, width=None, height=None, device=0):
+        self._pending = (camera_settings, device)
+        self._ctx = None
+        if width is not None:
+            super().__init__(camera_settings, width, height, 1, device)
+
+    def new_image(self, left, right, time_stamp):
+        if self._ctx is None:   # the reference learns the image size from the first frame
+            cam, device = self._pending
+            h, w = left.shape
+            super().__init__(cam, w, h, 1, device)
+        self.new_images([left], [right], [time_stamp])
