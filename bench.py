@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — tracked frames/s of the stereo-SVO hot path on MI355X.
+
+One step = StereoSlam::new_image (src/lib/stereo_slam.cpp:123-271) for every
+sequence a rank owns: pyramids -> sparse image alignment -> KLT -> reprojection
+GN -> SSD disparity -> depth filter (+ keyframe creation when it is due), on
+frames that are already resident in HBM. Workload at N=1: BASELINE.json
+configs[1] — EuRoC MH_02 class 752x480 stereo, 4-level SIA pyramid (6/2),
+~130-200 patches per frame — as seeded synthetic sequences (no dataset ships).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract of the driver) with `roofline` (dominant
+kernel, HIP-event time measured here) and `cpu_baseline` (the CPU oracle timed
+on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "stereo-svo-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+from stereo_svo_slam_amd import multi_seq, synth
+from stereo_svo_slam_amd.stereo_slam import StereoSlamBatch
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+STAGES = ("images+pyramids", "compaction", "sparse_align", "klt", "reproj_gn", "ssd_disparity",
+          "filter_update", "keyframe+readback")
+
+
+def algorithmic_bytes(cfg, n, n_active):
+    """ALGORITHMIC bytes of one tracked frame per stage."""
+    W, H = cfg["width"], cfg["height"]
+    L, lmin = cfg["max_pyramid_levels"], cfg["min_pyramid_level_pose_estimation"]
+    w = cfg["window_size_depth_calculator"]
+    wl = cfg["window_size_opt_flow"]
+    sx, sy = cfg["search_x"], cfg["search_y"]
+    b_p = 2 * W * H + sum((W >> l) * (H >> l) for l in range(1, L))
+    b_p += ((W + 1) // 2) * ((H + 1) // 2) + ((W + 3) // 4) * ((H + 3) // 4)
+    b_a = (L - lmin) * n_active * (64 + 36 + 20)
+    b_b = n * 3 * (2 * (wl + 2) ** 2) + n * (8 + 8 + 1 + 4)
+    b_r = n * (8 + 12 + 4)
+    b_c = n * (w * w + (w + sx) * (w + 2 * sy)) + n * (8 + 4)
+    b_d = n * (8 + 8 + 12 + 8 + 12 + 16)
+    return {"images+pyramids": b_p, "sparse_align": b_a, "klt": b_b, "reproj_gn": b_r,
+            "ssd_disparity": b_c, "filter_update": b_d}
+
+
+def render_sequences(cfg_name, seq_ids, n_frames, device):
+    """[n_seq][n_frames] uint8 CUDA tensors (left, right); scene = id % 8, path = id."""
+    cfg = dict(synth.CONFIGS[cfg_name])
+    scenes = {}
+    lefts, rights, ts = [], [], np.arange(n_frames, dtype=np.float32) / 20.0
+    for sid in seq_ids:
+        sc = scenes.setdefault(sid % 8, synth.Scene(sid % 8, device))
+        poses = synth.trajectory(n_frames, sid)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1234 + sid)
+        ls, rs = [], []
+        for k in range(n_frames):
+            l = sc.render(cfg, poses[k], False, 0.0)
+            r = sc.render(cfg, poses[k], True, 0.0)
+            # sensor noise, sigma = 1 grey level
+            l = (l.float() + torch.randn(l.shape, device=device, generator=gen)).round().clamp(0, 255).to(torch.uint8)
+            r = (r.float() + torch.randn(r.shape, device=device, generator=gen)).round().clamp(0, 255).to(torch.uint8)
+            ls.append(l.contiguous())
+            rs.append(r.contiguous())
+        lefts.append(ls)
+        rights.append(rs)
+    return cfg, lefts, rights, ts
+
+
+def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0):
+    """The CPU oracle (oracle/, single thread) on the first sequence: frames/s with the
+    reference's formula (time inside new_image only, src/app/slam_app.cpp:186-190)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    cam = O.make_camera(**{k: cfg[k] for k in synth.CAMERA_FIELDS})
+    slam = O.Slam(cam)
+    n = min(max_frames, len(lefts))
+    host = [(lefts[k].cpu().numpy(), rights[k].cpu().numpy()) for k in range(n)]
+    t_total, done, n_grad, t_sia = 0.0, 0, 0, 0.0
+    for k in range(n):
+        t0 = time.perf_counter()
+        slam.new_image(host[k][0], host[k][1], float(ts[k]))
+        dt = time.perf_counter() - t0
+        if k > 0:                       # like the GPU leg: the first (keyframe) frame is warm-up
+            t_total += dt
+            done += 1
+            st = slam.stats()
+            n_grad += st.sia_gradient_calls
+            t_sia += st.t_sia
+        if t_total > budget_s:
+            break
+    return {"value": done / t_total if t_total > 0 else None, "unit": "frames/s", "cores": 1,
+            "kind": "port",
+            "sample": f"oracle/ (C restatement, gcc -O3, 1 thread) on sequence 0, frames 1..{done} "
+                      f"of the same synthetic workload",
+            "gn_ms_per_iter": 1e3 * t_sia / max(n_grad, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
+    ap.add_argument("--seqs", type=int, default=64, help="sequences per GPU (share every launch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = multi_seq.init_distributed()
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    B, K, Wm = args.seqs, args.steps, max(args.warmup, 1)
+    n_frames = Wm + K
+    seq_ids = multi_seq.sequence_ids(rank, world, B)
+    t_setup = time.perf_counter()
+    cfg, lefts, rights, ts = render_sequences(args.config, seq_ids, n_frames, device)
+    torch.cuda.synchronize(device)
+    t_setup = time.perf_counter() - t_setup
+
+    slam = StereoSlamBatch(cfg, cfg["width"], cfg["height"], B, device.index)
+    slam.enable_timing(True)
+    packed = [slam.pack_images([lefts[s][k] for s in range(B)], [rights[s][k] for s in range(B)],
+                               [float(ts[k])] * B) for k in range(n_frames)]
+    marks = {}
+
+    def step_fn(k):
+        if k == Wm:
+            marks["t0"] = slam.totals()
+        slam.new_images_packed(packed[k])
+
+    seconds = multi_seq.timed_steps(step_fn, K, Wm, world, device)
+    t0, t1 = marks["t0"], slam.totals()
+    total_frames = B * K * world
+    fps = multi_seq.throughput(total_frames, seconds)
+    stage_ms = np.array(list(t1.stage_ms)) - np.array(list(t0.stage_ms))
+    counters = dict(frames=t1.frames - t0.frames, keyframes=t1.keyframes - t0.keyframes,
+                    n_kps=t1.keypoints - t0.keypoints,
+                    n_grad=t1.gn_gradient_calls - t0.gn_gradient_calls)
+
+    # one small exchange at the end: per-sequence summaries (id, frames, final pose)
+    local = [[sid, K + Wm] + [float(v) for v in slam.pose(i)] for i, sid in enumerate(seq_ids)]
+    summaries = multi_seq.gather_summaries(local, world, device)
+
+    if rank != 0:
+        return
+    mean_kps = counters["n_kps"] / max(counters["frames"], 1)
+    ab = algorithmic_bytes(cfg, mean_kps, mean_kps)
+    per_launch_ms = stage_ms / K
+    named = {STAGES[i]: float(per_launch_ms[i]) for i in range(8)}
+    kernel_stages = ("sparse_align", "klt", "reproj_gn", "ssd_disparity", "filter_update",
+                     "images+pyramids")
+    dom = max(kernel_stages, key=lambda s: named[s])
+    achieved = ab[dom] * B / (named[dom] * 1e-3) / 1e9 if named[dom] > 0 else 0.0
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": named[dom],
+                "stage_ms_per_step": named,
+                "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
+
+    single = None
+    if not args.no_single:
+        one = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1, device.index)
+        one.enable_timing(True)
+        sia_ms, n_grad = 0.0, 0
+        pk = [one.pack_images([lefts[0][k]], [rights[0][k]], [float(ts[k])]) for k in range(n_frames)]
+        for k in range(Wm):
+            one.new_images_packed(pk[k])
+        torch.cuda.synchronize(device)
+        a = one.totals()
+        tw = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            one.new_images_packed(pk[k])
+        tw = time.perf_counter() - tw
+        b = one.totals()
+        sia_ms = b.stage_ms[2] - a.stage_ms[2]
+        n_grad = b.gn_gradient_calls - a.gn_gradient_calls
+        single = {"frames_per_s": K / tw, "ms_per_frame": 1e3 * tw / K,
+                  "gn_ms_per_iter": sia_ms / max(n_grad, 1),
+                  "stage_ms_per_frame": {STAGES[i]: (b.stage_ms[i] - a.stage_ms[i]) / K for i in range(8)}}
+        one.close()
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(cfg, lefts[0], rights[0], ts, n_frames)
+
+    out = {
+        "metric": "tracked_frames_per_sec", "value": fps, "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: EuRoC MH_02 class {cfg['width']}x{cfg['height']} stereo, "
+                               f"{cfg['max_pyramid_levels'] - cfg['min_pyramid_level_pose_estimation']}-level SIA pyramid, "
+                               f"{mean_kps:.0f} patches/frame (synthetic, seeded)",
+                   "sequences_per_gpu": B, "frames_per_step": B * world,
+                   "keyframes_in_timed_region": counters["keyframes"],
+                   "gn_ms_per_iter": float(stage_ms[2] / max(counters["n_grad"] / B, 1)),
+                   "single_sequence": single, "setup_s": t_setup,
+                   "summaries_gathered": int(summaries.shape[0])},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

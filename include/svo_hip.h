@@ -148,10 +148,24 @@ typedef struct svo_frame_stats {
     float   pose_refined[6];
     float   sia_cost, reproj_cost;
     float   sia_ms;             /* device time of the sparse-alignment kernel (timing on) */
+    float   stage_ms[8];        /* HIP-event times on the ctx stream (timing on): images+pyramids,
+                                   compaction, sparse alignment, KLT, merge+reprojection GN,
+                                   SSD disparity, filter update, keyframe phase + read-back */
     svo_gn_trace sia_trace[SVO_MAX_PYRAMID_LEVELS];
     svo_gn_trace reproj_trace;
 } svo_frame_stats;
 int svo_get_frame_stats(svo_ctx *ctx, int seq, svo_frame_stats *out);
+/* counters accumulated over all sequences and all svo_new_images calls so far */
+typedef struct svo_totals {
+    int64_t frames;             /* sequence-frames processed                      */
+    int64_t keyframes;          /* of which created a keyframe                    */
+    int64_t keypoints;          /* sum of n_keypoints                             */
+    int64_t gn_gradient_calls;  /* sum of get_gradient calls of the sparse alignment */
+    int64_t gn_cost_calls;
+    double  stage_ms[8];        /* sum of svo_frame_stats.stage_ms (timing on)    */
+    double  wall_ms;            /* host wall time spent inside svo_new_images     */
+} svo_totals;
+int svo_get_totals(svo_ctx *ctx, svo_totals *out);
 int svo_ctx_enable_timing(svo_ctx *ctx, int on);
 
 #ifdef __cplusplus

@@ -791,18 +791,20 @@ void svo_o_ssd_disparity(const svo_image *left, const svo_image *right,
         if (tw <= 0 || th <= 0 || mw <= 0 || mh <= 0) continue; /* cv would throw */
         for (int k = 0; k < mh; k++)
             for (int j = 0; j < mw; j++) match[k * mw + j] = 0;
+        /* exact integer SSD; loop order chosen so that the innermost loop runs over
+         * the contiguous offsets j and vectorises (the order of integer adds is free) */
         for (int k = 0; k < mh; k++)
             for (int r = 0; r < th; r++) {
                 const uint8_t *t = left->data + (size_t)(y11 + r) * left->stride + x11;
                 const uint8_t *q = right->data + (size_t)(y21 + k + r) * right->stride + x21;
-                int32_t *m = match + k * mw;
-                for (int j = 0; j < mw; j++) {
-                    int32_t acc = 0;
-                    for (int c = 0; c < tw; c++) {
-                        const int d = (int)q[j + c] - (int)t[c];
-                        acc += d * d;
+                int32_t *restrict m = match + k * mw;
+                for (int c = 0; c < tw; c++) {
+                    const int tv = t[c];
+                    const uint8_t *restrict qq = q + c;
+                    for (int j = 0; j < mw; j++) {
+                        const int d = (int)qq[j] - tv;
+                        m[j] += d * d;
                     }
-                    m[j] += acc;
                 }
             }
         /* minMaxLoc on the float map */

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -203,9 +204,10 @@ struct svo_ctx {
     int* d_n_all = nullptr;      // [B*2]
     size_t sia_lds = 0;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev[10] = {nullptr};
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
+    svo_totals totals;
 };
 
 namespace {
@@ -353,6 +355,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
     svo_ctx* c = new (std::nothrow) svo_ctx();
     if (!c) return svo_set_error(SVO_ERR_INVALID, "out of host memory");
     c->device = device; c->B = n_sequences; c->width = width; c->height = height; c->cam = *cam;
+    std::memset(&c->totals, 0, sizeof(c->totals));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int cells = (width / cam->grid_width) * (height / cam->grid_height);
     c->cap = (int)align_up((size_t)(2 * cells + 128), 64);
@@ -405,8 +408,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_res), sizeof(FrameResult) * B, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_n), sizeof(int) * 2 * B, hipHostMallocDefault));
     if ((rc = dev_alloc(c, &c->d_n_all, (size_t)2 * B))) return rc;
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
+    for (int i = 0; i < 10; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
     c->seqs.resize(B);
     for (int s = 0; s < B; s++) {
@@ -451,8 +453,8 @@ extern "C" int svo_ctx_destroy(svo_ctx* c) {
     if (c->h_args) (void)hipHostFree(c->h_args);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_n) (void)hipHostFree(c->h_n);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < 10; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     // ImageSet structs: owned by the free lists, the current/previous pointers and keyframes
     for (Seq& q : c->seqs) {
         std::vector<ImageSet*> all(q.free_sets);
@@ -541,10 +543,13 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     if (!c || !left || !right || !time_stamps || stride < c->width)
         return svo_set_error(SVO_ERR_INVALID, "svo_new_images: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
+    const auto wall0 = std::chrono::steady_clock::now();
     const int B = c->B;
     const hipMemcpyKind kind = mem == SVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const bool first = c->seqs[0].frame_id < 0;
     int rc;
+#define SVO_MARK(i) do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[i], c->stream)); } while (0)
+    SVO_MARK(0);
 
     // ---- images in, pyramids
     for (int s = 0; s < B; s++) {
@@ -639,14 +644,19 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         HIP_TRY(hipMemsetAsync(c->d_res, 0, sizeof(FrameResult) * B, c->stream));
         if ((rc = enqueue_keyframes(c, need, true))) return rc;
     } else {
+        SVO_MARK(1);
         launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
-        if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        SVO_MARK(2);
         launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->sia_lds, c->cap, c->stream);
-        if (c->timing) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, c->cap, c->cam.window_size_opt_flow, c->stream);
+        SVO_MARK(4);
         launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), B, c->stream);
+        SVO_MARK(5);
         launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, c->cap, c->stream);
+        SVO_MARK(6);
         launch_filter(dargs_at<FilterArgs>(c, c->off_filt), B, c->stream);
+        SVO_MARK(7);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -663,8 +673,18 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     HIP_TRY(hipMemcpyAsync(c->h_n, c->d_n_all, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 
-    float sia_ms = 0;
-    if (c->timing && !first) (void)hipEventElapsedTime(&sia_ms, c->ev0, c->ev1);
+    SVO_MARK(8);
+    float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c->timing) {
+        HIP_TRY(hipEventSynchronize(c->ev[8]));
+        if (!first) {
+            for (int i = 0; i < 7; i++) (void)hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]);
+            (void)hipEventElapsedTime(&stage_ms[7], c->ev[7], c->ev[8]);
+        } else {
+            (void)hipEventElapsedTime(&stage_ms[7], c->ev[0], c->ev[8]);
+        }
+    }
+    const float sia_ms = stage_ms[2];
 
     // ---- host bookkeeping: pose filter, trajectory (stereo_slam.cpp:250-270)
     for (int s = 0; s < B; s++) {
@@ -705,10 +725,28 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         std::memcpy(st.pose_sia, r.pose_sia, sizeof(st.pose_sia));
         std::memcpy(st.pose_refined, r.pose_refined, sizeof(st.pose_refined));
         st.sia_cost = r.sia_cost; st.reproj_cost = r.reproj_cost; st.sia_ms = sia_ms;
+        std::memcpy(st.stage_ms, stage_ms, sizeof(stage_ms));
         std::memcpy(st.sia_trace, r.sia_trace, sizeof(st.sia_trace));
         st.reproj_trace = r.reproj_trace;
+        c->totals.frames++;
+        c->totals.keyframes += need[s];
+        c->totals.keypoints += q.n_host;
+        if (!first)
+            for (int l = 0; l < SVO_MAX_PYRAMID_LEVELS; l++) {
+                c->totals.gn_gradient_calls += r.sia_trace[l].n_gradient;
+                c->totals.gn_cost_calls += r.sia_trace[l].n_cost;
+            }
         if (r.overflow) return svo_set_error(SVO_ERR_CAPACITY, "sequence %d: more than %d keypoints", s, c->cap);
     }
+    for (int i = 0; i < 8; i++) c->totals.stage_ms[i] += stage_ms[i];
+    c->totals.wall_ms +=
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return SVO_OK;
+}
+
+extern "C" int svo_get_totals(svo_ctx* c, svo_totals* out) {
+    if (!c || !out) return svo_set_error(SVO_ERR_INVALID, "svo_get_totals: bad arguments");
+    *out = c->totals;
     return SVO_OK;
 }
 

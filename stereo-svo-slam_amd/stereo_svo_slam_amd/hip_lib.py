@@ -23,6 +23,7 @@ SYMBOLS = (
     "svo_ctx_create", "svo_ctx_destroy", "svo_new_images", "svo_new_image", "svo_get_pose",
     "svo_get_frame_keypoints", "svo_get_keyframe_count", "svo_get_keyframe",
     "svo_get_trajectory", "svo_update_pose", "svo_get_frame_stats", "svo_ctx_enable_timing",
+    "svo_get_totals",
 )
 
 

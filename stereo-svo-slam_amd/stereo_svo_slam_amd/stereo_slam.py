@@ -36,7 +36,15 @@ class FrameStats(C.Structure):
                 ("n_keyframes", C.c_int32), ("inside_count", C.c_int32), ("overflow", C.c_int32),
                 ("pose_sia", C.c_float * 6), ("pose_refined", C.c_float * 6),
                 ("sia_cost", C.c_float), ("reproj_cost", C.c_float), ("sia_ms", C.c_float),
+                ("stage_ms", C.c_float * 8),
                 ("sia_trace", GnTrace * 8), ("reproj_trace", GnTrace)]
+
+
+class Totals(C.Structure):
+    """svo_totals (include/svo_hip.h)."""
+    _fields_ = [("frames", C.c_int64), ("keyframes", C.c_int64), ("keypoints", C.c_int64),
+                ("gn_gradient_calls", C.c_int64), ("gn_cost_calls", C.c_int64),
+                ("stage_ms", C.c_double * 8), ("wall_ms", C.c_double)]
 
 
 class Frame:
@@ -101,6 +109,28 @@ class StereoSlamBatch:
             torch.cuda.current_stream(self.device).synchronize()
         ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
         _check(lib().svo_new_images(self._ctx, ptrs_l, ptrs_r, stride, ts, 1 if on_dev else 0))
+
+    def pack_images(self, lefts, rights, time_stamps):
+        """Pre-build the argument arrays of one step for device-resident frames
+        (keeps Python out of a timed loop); pass the result to new_images_packed."""
+        ptrs_l = (C.c_void_p * self.n)()
+        ptrs_r = (C.c_void_p * self.n)()
+        stride = lefts[0].stride(0)
+        for s in range(self.n):
+            for arr, dst in ((lefts[s], ptrs_l), (rights[s], ptrs_r)):
+                assert arr.is_cuda and arr.dtype == torch.uint8 and arr.stride(1) == 1
+                assert tuple(arr.shape) == (self.height, self.width) and arr.stride(0) == stride
+                dst[s] = arr.data_ptr()
+        ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
+        return ptrs_l, ptrs_r, stride, ts, (lefts, rights)
+
+    def new_images_packed(self, packed):
+        _check(lib().svo_new_images(self._ctx, packed[0], packed[1], packed[2], packed[3], 1))
+
+    def totals(self):
+        t = Totals()
+        _check(lib().svo_get_totals(self._ctx, C.byref(t)))
+        return t
 
     def pose(self, seq=0):
         p = np.zeros(6, np.float32)
