@@ -1,0 +1,280 @@
+"""CPU tests (no GPU): the oracle against the reference's own known answers,
+against independent numpy/scipy formulations of the OpenCV primitives it
+restates, and against the committed golden vectors (tests/golden/)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+from scipy import ndimage
+from scipy.spatial.transform import Rotation
+
+import oracle_py as O
+from stereo_svo_slam_amd import synth
+import util
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+# ------------------------------------------------ the reference's known answer
+def test_exponential_map_known_answer():
+    """src/test/test_exponential_map.cpp:35-48: twist (0.1,0.2,0.3 | 0.4,0.5,0.6).
+    The shipped header (src/include/exponential_map.hpp:14-35) writes the mapped
+    translation into rows 0..2 and keeps w in rows 3..5."""
+    out = O.exponential_map([0.1, 0.2, 0.3, 0.4, 0.5, 0.6])
+    expect = [0.12187591059875308, 0.173369312443241, 0.30760829923146377]
+    assert np.all(np.abs(out[:3] - expect) < 0.01)          # the reference's tolerance
+    assert np.all(np.abs(out[:3] - expect) < 1e-6)          # and float accuracy
+    assert np.array_equal(out[3:], np.float32([0.4, 0.5, 0.6]))
+
+
+def test_exponential_map_closed_form():
+    """src/test/exponential_map_test.py: (I + (1-cos1) K + (1-sin1) K^2) v."""
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        t = rng.normal(0, 0.3, 6)
+        w = t[3:]
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        v = (np.eye(3) + (1 - np.cos(1.0)) * K + (1 - np.sin(1.0)) * K @ K) @ t[:3]
+        out = O.exponential_map(t)
+        assert np.allclose(out[:3], v, atol=1e-6)
+
+
+# ------------------------------------------------------ restated OpenCV pieces
+def test_rodrigues_matches_scipy():
+    rng = np.random.RandomState(1)
+    for _ in range(50):
+        r = rng.normal(0, 0.5, 3).astype(np.float32)
+        R = O.rodrigues(r)
+        assert np.allclose(R, Rotation.from_rotvec(r.astype(np.float64)).as_matrix(), atol=1e-12)
+    assert np.array_equal(O.rodrigues([0, 0, 0]), np.eye(3))
+
+
+def test_inv_svd_is_the_inverse_and_zero_for_zero():
+    rng = np.random.RandomState(2)
+    for _ in range(20):
+        J = rng.normal(0, 1, (40, 6))
+        H = (J.T @ J).astype(np.float32)
+        Hi, ok = O.inv_svd(H)
+        assert ok
+        assert np.allclose(Hi @ H.astype(np.float64), np.eye(6), atol=5e-3)
+    Hi, ok = O.inv_svd(np.zeros((6, 6), np.float32))
+    assert not ok and np.all(Hi == 0)
+
+
+def test_solve_svd_least_squares():
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        A = rng.normal(0, 1, (3, 2)).astype(np.float32)
+        b = rng.normal(0, 1, 3).astype(np.float32)
+        x = O.solve_svd(A, b)
+        ref = np.linalg.lstsq(A.astype(np.float64), b.astype(np.float64), rcond=None)[0]
+        assert np.allclose(x, ref, atol=1e-4)
+
+
+def test_project_keypoints_formula():
+    cfg = dict(synth.CONFIGS["econ"])           # non-zero distortion
+    cam = util.oracle_camera(cfg)
+    rng = np.random.RandomState(4)
+    P = np.stack([rng.uniform(-1, 1, 50), rng.uniform(-1, 1, 50), rng.uniform(2, 6, 50)], 1).astype(np.float32)
+    pose = np.float32([0.1, -0.05, 0.2, 0.02, -0.03, 0.01])
+    out = O.project_keypoints(pose, P, cam)
+    R = Rotation.from_rotvec(-pose[3:].astype(np.float64)).as_matrix()
+    X = (R @ (P - pose[:3]).astype(np.float64).T).T
+    x, y = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2]
+    r2 = x * x + y * y
+    c = 1 + cfg["k1"] * r2 + cfg["k2"] * r2 ** 2 + cfg["k3"] * r2 ** 3
+    xd = x * c + 2 * cfg["p1"] * x * y + cfg["p2"] * (r2 + 2 * x * x)
+    yd = y * c + cfg["p1"] * (r2 + 2 * y * y) + 2 * cfg["p2"] * x * y
+    ref = np.stack([cfg["fx"] * xd + cfg["cx"], cfg["fy"] * yd + cfg["cy"]], 1)
+    assert np.allclose(out, ref, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (5, 7)])
+def test_halfsample_pyramid(shape):
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, shape).astype(np.uint8)
+    lv = O.build_pyramid(img, 3)
+    a = img.astype(np.int32)
+    for l in (1, 2):
+        h, w = a.shape[0] // 2, a.shape[1] // 2
+        a = (a[0:2 * h:2, 0:2 * w:2] + a[0:2 * h:2, 1:2 * w:2] + a[1:2 * h:2, 0:2 * w:2] + a[1:2 * h:2, 1:2 * w:2]) // 4
+        assert np.array_equal(lv[l], a.astype(np.uint8))
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (9, 11)])
+def test_pyr_down_vs_scipy(shape):
+    """cv::pyrDown: 5x5 binomial, reflect-101 ('mirror'), round half up, take even samples."""
+    rng = np.random.RandomState(6)
+    img = rng.randint(0, 256, shape).astype(np.uint8)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    f = ndimage.correlate1d(img.astype(np.int64), k, axis=0, mode="mirror")
+    f = ndimage.correlate1d(f, k, axis=1, mode="mirror")
+    ref = ((f + 128) >> 8)[::2, ::2].astype(np.uint8)
+    assert np.array_equal(O.pyr_down(img), ref)
+
+
+def test_scharr_vs_scipy():
+    rng = np.random.RandomState(7)
+    img = rng.randint(0, 256, (40, 56)).astype(np.uint8).astype(np.int64)
+    sm, df = np.array([3, 10, 3]), np.array([-1, 0, 1])
+    dx = ndimage.correlate1d(ndimage.correlate1d(img, sm, axis=0, mode="mirror"), df, axis=1, mode="mirror")
+    dy = ndimage.correlate1d(ndimage.correlate1d(img, df, axis=0, mode="mirror"), sm, axis=1, mode="mirror")
+    out = O.scharr(img.astype(np.uint8))
+    assert np.array_equal(out[..., 0], dx) and np.array_equal(out[..., 1], dy)
+
+
+def test_sobel_and_fast_brute_force():
+    rng = np.random.RandomState(8)
+    img = (ndimage.gaussian_filter(rng.uniform(0, 255, (60, 80)), 1.5) * 2 % 256).astype(np.uint8)
+    a = img.astype(np.int64)
+    k = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    ref = np.clip(ndimage.correlate(a, k, mode="mirror"), 0, 255).astype(np.uint8)
+    assert np.array_equal(O.sobel_x_u8(img), ref)
+    # FAST-9/16: brute-force arc test + score = max_t such that still a corner
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3),
+            (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+    def is_corner(y, x, t):
+        d = [int(img[y, x]) - int(img[y + dy, x + dx]) for dx, dy in ring]
+        for s in range(16):
+            arc = [d[(s + i) % 16] for i in range(9)]
+            if all(v > t for v in arc) or all(v < -t for v in arc):
+                return True
+        return False
+
+    raw = np.zeros(img.shape, np.int32)
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            if is_corner(y, x, 6):
+                t = 6
+                while is_corner(y, x, t + 1):
+                    t += 1
+                raw[y, x] = t
+    ref = np.zeros(img.shape, np.uint8)
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            s = raw[y, x]
+            nb = raw[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if s and s > nb.max():
+                ref[y, x] = s
+    got = O.fast_score_nms(img, 6)
+    assert (ref > 0).sum() > 5
+    assert np.array_equal(got, ref)
+
+
+def test_ssd_disparity_brute_force():
+    rng = np.random.RandomState(9)
+    left = rng.randint(0, 256, (60, 90)).astype(np.uint8)
+    right = np.roll(left, 5, axis=1)
+    kps = np.float32([[30.4, 30.9], [3, 3], [88, 58], [45, 10]])
+    win, sx, sy = 11, 12, 2
+    got = O.ssd_disparity(left, right, kps, win, sx, sy, 1)
+    wb, wa = win // 2, (win + 1) // 2
+    for i, (kx, ky) in enumerate(kps):
+        x, y = int(kx), int(ky)
+        x11, x12 = max(0, x - wb), min(89, x + wa)
+        y11, y12 = max(0, y - wb), min(60, y + wa)
+        x22 = min(89, x + wa + sx)
+        y21, y22 = max(0, y - wb - sy), min(59, y + wa + sy)
+        t = left[y11:y12, x11:x12].astype(np.int64)
+        roi = right[y21:y22, x11:x22].astype(np.int64)
+        mh, mw = roi.shape[0] - t.shape[0] + 1, roi.shape[1] - t.shape[1] + 1
+        m = np.array([[((roi[k:k + t.shape[0], j:j + t.shape[1]] - t) ** 2).sum() for j in range(mw)]
+                      for k in range(mh)]).astype(np.float32)
+        ky0, kx0 = np.unravel_index(np.argmin(m), m.shape)
+        sel = [j for j in range(kx0, mw) for k in range(ky0, mh) if m[k, j] <= m[ky0, kx0]]
+        assert got[i] == max(0.5, np.float32(sum(sel)) / len(sel))
+    assert got[0] == 5.0
+
+
+def test_klt_recovers_translation():
+    sc = util.scenario("tiny", 2, 0, 1)
+    img = sc["L"][0]
+    shifted = ndimage.shift(img.astype(np.float64), (1.5, -2.25), order=1, mode="mirror")
+    shifted = np.clip(np.round(shifted), 0, 255).astype(np.uint8)
+    win = 21
+    a, b = O.build_lk_pyramid(img, win), O.build_lk_pyramid(shifted, win)
+    rng = np.random.RandomState(10)
+    pts = np.stack([rng.uniform(40, 280, 60), rng.uniform(40, 200, 60)], 1).astype(np.float32)
+    out, st, err = O.klt_track(a, b, pts, pts.copy(), win)
+    good = st > 0
+    assert good.sum() >= 50
+    flow = (out - pts)[good]
+    assert np.abs(np.median(flow[:, 0]) + 2.25) < 0.1 and np.abs(np.median(flow[:, 1]) - 1.5) < 0.1
+    assert np.all(err[good] < 10) and np.all(np.isinf(err[~good]))
+
+
+def test_depth_filter_kalman_step():
+    x, P = O.kf1_update(0.5, 0.04, 1e-4, 0.01, 0.6)
+    Pp = 0.04 + 1e-4
+    K = Pp / (Pp + 0.01)
+    assert abs(x - (0.5 + K * 0.1)) < 1e-6 and abs(P - (1 - K) * Pp) < 1e-7
+
+
+def test_pose_filter_matches_float64_kalman():
+    cfg = dict(synth.CONFIGS["tiny"])
+    s = O.Slam(util.oracle_camera(cfg))
+    x, P = np.zeros(12), np.eye(12)
+    Q = 100 * np.eye(12)
+    rng = np.random.RandomState(11)
+    for i in range(6):
+        dt = 0.0 if i % 2 == 0 else 0.05
+        A = np.eye(12)
+        A[:6, 6:] = dt * np.eye(6)
+        z = rng.normal(0, 0.2, 12)
+        R = np.diag([0.1] * 6 + [1.0] * 6)
+        x, P = A @ x, A @ P @ A.T + Q
+        K = P @ np.linalg.inv(P + R)
+        x, P = x + K @ (z - x), P - K @ P
+        out = s.update_pose(z[:6], z[6:], [0.1] * 6, [1.0] * 6, dt)
+        assert np.allclose(out, x[:6], atol=1e-4)
+
+
+# -------------------------------------------------------------- system level
+def test_oracle_tracker_follows_ground_truth():
+    """Thesis-level envelope (doc/doc.tex:1231-1257: cm / sub-degree errors) on a synthetic
+    sequence: the restated pipeline tracks the known camera path."""
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", 14, 0, device="cpu")
+    s = O.Slam(util.oracle_camera(cfg))
+    for k in range(14):
+        s.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        k2, k3, info = s.keypoints()
+        assert np.all(k3[:, 2] > 0) or k > 0               # intent of test_depth_calculator.cpp:56-58
+        if k >= 3:
+            assert np.max(np.abs(s.pose()[:3] - poses[k][:3])) < 0.06  # y and rx are weakly separable at 320x240
+            assert np.max(np.abs(s.pose()[3:] - poses[k][3:])) < 0.03
+    assert s.num_keyframes() >= 1
+
+
+def test_first_keyframe_one_keypoint_per_cell():
+    """Intent of the stale test_corner_detector.cpp:24-66: one keypoint per grid box."""
+    left, right = util.real_pair()
+    kps, score, typ = O.detect_keypoints(left, 40, 50, 0)
+    assert len(kps) == (752 // 40) * (480 // 50)
+    cells = {(int(x) // 40, int(y) // 50) for x, y in kps}
+    assert len(cells) == len(kps)
+
+
+# ------------------------------------------------------------- golden vectors
+def test_golden_vectors_real_pair():
+    g = np.load(os.path.join(util.GOLDEN, "golden_real_pair.npz"))
+    left, right = util.real_pair()
+    assert np.array_equal(np.array([crc(p) for p in O.build_pyramid(left, 6)], np.uint32), g["pyr_crc"])
+    lk = O.build_lk_pyramid(left, 31)
+    assert np.array_equal(np.array([crc(p) for p in lk], np.uint32), g["lk_crc"])
+    assert np.array_equal(np.array([crc(O.scharr(p)) for p in lk], np.uint32), g["scharr_crc"])
+    assert np.array_equal(O.ssd_disparity(left, right, g["kps"], 31, 60, 6, 1), g["disp_31"])
+    assert np.array_equal(O.ssd_disparity(left, right, g["kps"], 35, 60, 6, 1), g["disp_35"])
+    pts, st, err = O.klt_track(lk, O.build_lk_pyramid(right, 31), g["kps"],
+                               (g["kps"] + np.float32([10, 0])).astype(np.float32), 31)
+    assert np.array_equal(st, g["klt_status"]) and np.array_equal(pts, g["klt_pts"])
+    assert np.array_equal(err, g["klt_err"])
+    assert crc(O.fast_score_nms(left, 6)) == g["fast_crc"]
+    dk, ds, dt = O.detect_keypoints(left, 40, 50, 0)
+    assert np.array_equal(dk, g["det_kps"]) and np.array_equal(dt, g["det_type"])
+    # the real pair is a plausible stereo pair: most disparities are positive and finite
+    assert (g["disp_31"] > 0.5).mean() > 0.8
