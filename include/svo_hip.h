@@ -40,6 +40,12 @@ int svo_handle_create(int device, int max_keypoints, svo_handle **out);
 int svo_handle_destroy(svo_handle *h);
 int svo_handle_set_stream(svo_handle *h, void *hip_stream); /* hipStream_t, NULL = default */
 int svo_handle_synchronize(svo_handle *h);
+/* The Gauss-Newton steps need pinv(J^T J) b (Matx66f::inv(DECOMP_SVD),
+ * src/lib/pose_estimator.cpp:405, pose_refinement.cpp:398). Default (0): a
+ * positive definite 6x6 system is solved by LDL^T in double and only rank
+ * deficient ones take the reference's Jacobi-SVD route; 1: always the SVD
+ * route (slower; reproduces the reference's iteration trace). */
+int svo_handle_set_exact_pinv(svo_handle *h, int on);
 
 /* ---- stage level entry points (one per row of SURVEY §8a) ----------------
  * P1  createImgPyramid / halfSample          src/lib/stereo_slam.cpp:93-121
@@ -167,6 +173,7 @@ typedef struct svo_totals {
 } svo_totals;
 int svo_get_totals(svo_ctx *ctx, svo_totals *out);
 int svo_ctx_enable_timing(svo_ctx *ctx, int on);
+int svo_ctx_set_exact_pinv(svo_ctx *ctx, int on);   /* see svo_handle_set_exact_pinv */
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,21 @@
 
 namespace svo {
 
-constexpr int SSD_MAX_WIN = 36;
-constexpr int SSD_MAX_ROI_W = 36 + 64 + 4;   // win + search_x, padded
-constexpr int SSD_MAX_ROI_H = 36 + 2 * 8;    // win + 2*search_y
+constexpr int SSD_MAX_WIN = 36;                 // template edge (window <= 35)
+constexpr int SSD_TW4 = 9;                      // dwords per template row
+constexpr int SSD_T_STRIDE = 12;                // dwords (48 B: three aligned 16 B reads)
+constexpr int SSD_T_ROWS = SSD_MAX_WIN + 6;     // 3 zero rows before and after
+constexpr int SSD_R_STRIDE = 112;               // bytes per search-region row (>= 35+64+pad)
+constexpr int SSD_R_ROWS = SSD_MAX_WIN + 16 + 4;
 constexpr int SSD_MAX_MATCH = 65 * 17;
 
+// C1. One workgroup per keypoint. The template (zero padded to whole dwords)
+// and the search region sit in LDS. A work item is 4 vertically adjacent
+// offsets (k0..k0+3, j): every search-region row is read once (10 dwords,
+// funnel-shifted to the column phase j&3 with v_alignbyte), squared once
+// (v_dot4_u32_u8 with itself) and multiplied against the 4 template rows it
+// meets (v_dot4_u32_u8), so SSD = sum a^2 - 2 sum a*t + sum t^2 costs ~0.7
+// instructions per pixel pair and stays an exact integer.
 __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
     const SsdArgs& a = args[blockIdx.y];
     if (a.enable && !*a.enable) return;
@@ -28,9 +38,10 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     if (kp >= n) return;
     const int tid = threadIdx.x;
 
-    __shared__ uint8_t s_t[SSD_MAX_WIN * SSD_MAX_WIN];
-    __shared__ uint8_t s_r[SSD_MAX_ROI_H * SSD_MAX_ROI_W];
+    __shared__ __attribute__((aligned(16))) uint32_t s_t[SSD_T_ROWS * SSD_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_r[SSD_R_ROWS * SSD_R_STRIDE];
     __shared__ int s_m[SSD_MAX_MATCH];
+    __shared__ uint32_t s_tt[SSD_MAX_WIN];
     __shared__ unsigned long long s_key[4];
     __shared__ int s_sum[4], s_cnt[4];
 
@@ -52,39 +63,110 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     if (a.clamp_half && (x12 <= 0 || y12 <= 0 || x11 >= cols - 1 || y11 >= rows - 1)) skip = true;
     if (a.clamp_half && (x22 <= 0 || y22 <= 0 || x21 >= cols - 1 || y21 >= rows - 1)) skip = true;
     if (tw <= 0 || th <= 0 || mw <= 0 || mh <= 0) skip = true;
-    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || rw > SSD_MAX_ROI_W || rh > SSD_MAX_ROI_H ||
+    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || rw > SSD_R_STRIDE - 12 || rh > SSD_R_ROWS - 4 ||
         mw * mh > SSD_MAX_MATCH)
-        skip = true;  // host validates window sizes; never taken with valid settings
+        skip = true;  // the host validates window sizes; never taken with valid settings
     if (skip) {
         if (tid == 0) a.disparity[kp] = -1.0f;
         return;
     }
 
-    for (int i = tid; i < tw * th; i += 256) {
-        const int r = i / tw, c = i % tw;
-        s_t[r * SSD_MAX_WIN + c] = a.left.data[(size_t)(y11 + r) * a.left.stride + x11 + c];
+    // ---- stage template (rows -3..th+2, zero outside) and search region (zero outside)
+    for (int i = tid; i < SSD_T_ROWS * SSD_T_STRIDE; i += 256) {
+        const int r = i / SSD_T_STRIDE - 3, d = i % SSD_T_STRIDE;
+        uint32_t v = 0;
+        if (r >= 0 && r < th) {
+            const uint8_t* src = a.left.data + (size_t)(y11 + r) * a.left.stride + x11 + 4 * d;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * d + b < tw) v |= (uint32_t)src[b] << (8 * b);
+        }
+        s_t[i] = v;
     }
-    for (int i = tid; i < rw * rh; i += 256) {
-        const int r = i / rw, c = i % rw;
-        s_r[r * SSD_MAX_ROI_W + c] = a.right.data[(size_t)(y21 + r) * a.right.stride + x21 + c];
+    for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 4); i += 256) {
+        const int r = i / (SSD_R_STRIDE / 4), d = i % (SSD_R_STRIDE / 4);
+        uint32_t v = 0;
+        if (r < rh) {
+            const uint8_t* src = a.right.data + (size_t)(y21 + r) * a.right.stride + x21 + 4 * d;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * d + b < rw) v |= (uint32_t)src[b] << (8 * b);
+        }
+        reinterpret_cast<uint32_t*>(s_r)[i] = v;
+    }
+    __syncthreads();
+    if (tid < th) {
+        uint32_t tt = 0;
+#pragma unroll
+        for (int d = 0; d < SSD_TW4; d++) {
+            const uint32_t t = s_t[(tid + 3) * SSD_T_STRIDE + d];
+            tt = __builtin_amdgcn_udot4(t, t, tt, false);
+        }
+        s_tt[tid] = tt;
+    }
+    __syncthreads();
+    uint32_t stt = 0;
+    for (int r = 0; r < th; r++) stt += s_tt[r];
+
+    // masks that cut the search-region dwords to the template width
+    uint32_t msk[SSD_TW4];
+#pragma unroll
+    for (int d = 0; d < SSD_TW4; d++) {
+        const int rem = tw - 4 * d;
+        msk[d] = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+    }
+
+    const int ngroups = (mh + 3) >> 2;
+    for (int item = tid; item < ngroups * mw; item += 256) {
+        const int kg = item / mw, j = item - kg * mw;
+        const int k0 = kg * 4;
+        const unsigned shift = (unsigned)(j & 3);
+        const uint32_t* rbase = reinterpret_cast<const uint32_t*>(s_r) + (j >> 2);
+        uint32_t sab0 = 0, sab1 = 0, sab2 = 0, sab3 = 0;
+        uint32_t saa0 = 0, saa1 = 0, saa2 = 0, saa3 = 0;
+        for (int st = 0; st < th + 3; st++) {
+            const uint32_t* rr = rbase + (k0 + st) * (SSD_R_STRIDE / 4);
+            uint32_t w[SSD_TW4 + 1];
+#pragma unroll
+            for (int d = 0; d <= SSD_TW4; d++) w[d] = rr[d];
+            uint32_t av[SSD_TW4];
+            uint32_t rowsq = 0;
+#pragma unroll
+            for (int d = 0; d < SSD_TW4; d++) {
+                // funnel shift by the column phase j & 3 (bytes)
+                uint32_t v = __builtin_amdgcn_alignbyte(w[d + 1], w[d], shift);
+                v &= msk[d];
+                av[d] = v;
+                rowsq = __builtin_amdgcn_udot4(v, v, rowsq, false);
+            }
+            // this region row meets template row st - i for offset k0 + i
+            const uint32_t* t0 = &s_t[(st + 3) * SSD_T_STRIDE];
+            const uint32_t* t1 = t0 - SSD_T_STRIDE;
+            const uint32_t* t2 = t1 - SSD_T_STRIDE;
+            const uint32_t* t3 = t2 - SSD_T_STRIDE;
+#pragma unroll
+            for (int d = 0; d < SSD_TW4; d++) {
+                sab0 = __builtin_amdgcn_udot4(av[d], t0[d], sab0, false);
+                sab1 = __builtin_amdgcn_udot4(av[d], t1[d], sab1, false);
+                sab2 = __builtin_amdgcn_udot4(av[d], t2[d], sab2, false);
+                sab3 = __builtin_amdgcn_udot4(av[d], t3[d], sab3, false);
+            }
+            saa0 += (st < th) ? rowsq : 0u;
+            saa1 += (st >= 1 && st - 1 < th) ? rowsq : 0u;
+            saa2 += (st >= 2 && st - 2 < th) ? rowsq : 0u;
+            saa3 += (st >= 3) ? rowsq : 0u;
+        }
+        if (k0 + 0 < mh) s_m[(k0 + 0) * mw + j] = (int)(saa0 + stt - 2u * sab0);
+        if (k0 + 1 < mh) s_m[(k0 + 1) * mw + j] = (int)(saa1 + stt - 2u * sab1);
+        if (k0 + 2 < mh) s_m[(k0 + 2) * mw + j] = (int)(saa2 + stt - 2u * sab2);
+        if (k0 + 3 < mh) s_m[(k0 + 3) * mw + j] = (int)(saa3 + stt - 2u * sab3);
     }
     __syncthreads();
 
     const int nm = mw * mh;
     unsigned long long best = ~0ull;
     for (int o = tid; o < nm; o += 256) {
-        const int k = o / mw, j = o % mw;
-        int acc = 0;
-        for (int r = 0; r < th; r++) {
-            const uint8_t* t = &s_t[r * SSD_MAX_WIN];
-            const uint8_t* q = &s_r[(k + r) * SSD_MAX_ROI_W + j];
-            for (int c = 0; c < tw; c++) {
-                const int d = (int)q[c] - (int)t[c];
-                acc += d * d;
-            }
-        }
-        s_m[o] = acc;
-        const unsigned long long key = ((unsigned long long)(unsigned)acc << 32) | (unsigned)o;
+        const unsigned long long key = ((unsigned long long)(unsigned)s_m[o] << 32) | (unsigned)o;
         best = key < best ? key : best;
     }
     // first minimum in row-major order == smallest (value, index) key

@@ -84,17 +84,12 @@ __device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6],
     }
     block_reduce<27, RP_THREADS>(v, sh.red, sh.sums);
     if (tid == 0) {
-        float H[36], Hinv[36], e[6], twist[6];
+        float H[36], e[6], twist[6];
         int idx = 0;
         for (int r = 0; r < 6; r++)
             for (int c = r; c < 6; c++) { H[r * 6 + c] = sh.sums[idx]; H[c * 6 + r] = sh.sums[idx]; idx++; }
         for (int r = 0; r < 6; r++) e[r] = sh.sums[21 + r];
-        inv_svd6(H, Hinv);
-        for (int r = 0; r < 6; r++) {
-            float s = 0;
-            for (int c = 0; c < 6; c++) s += Hinv[r * 6 + c] * e[c];
-            twist[r] = s;
-        }
+        gn_solve6(H, e, twist, a.exact_pinv != 0);
         exponential_map(twist, sh.grad);   // not rotated (pose_refinement.cpp:398-411)
     }
     __syncthreads();

@@ -165,17 +165,12 @@ __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx& L, const f
     }
     block_reduce<27, SIA_THREADS>(v, sh.red, sh.sums);
     if (tid == 0) {
-        float H[36], Hinv[36], b[6], delta[6], pg[6];
+        float H[36], b[6], delta[6], pg[6];
         int q = 0;
         for (int r = 0; r < 6; r++)
             for (int c = r; c < 6; c++) { H[r * 6 + c] = sh.sums[q]; H[c * 6 + r] = sh.sums[q]; q++; }
         for (int r = 0; r < 6; r++) b[r] = sh.sums[21 + r];
-        inv_svd6(H, Hinv);
-        for (int r = 0; r < 6; r++) {
-            float s = 0;
-            for (int c = 0; c < 6; c++) s += Hinv[r * 6 + c] * b[c];
-            delta[r] = s;
-        }
+        gn_solve6(H, b, delta, a.exact_pinv != 0);
         exponential_map(delta, pg);
         mat33f_vec(sh.pm.R, pg, sh.grad);            // pose_estimator.cpp:495-497
         mat33f_vec(sh.pm.R, pg + 3, sh.grad + 3);

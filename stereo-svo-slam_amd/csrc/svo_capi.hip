@@ -51,6 +51,7 @@ struct svo_handle {
     float4* sia_cache;   // [max_kps*16]
     float* sia_kpws;     // [max_kps*8]
     KfDev* kf_one;       // 1-entry keyframe table for svo_klt_track
+    int exact_pinv;
 };
 
 extern "C" const char* svo_last_error(void) { return g_err; }
@@ -68,6 +69,7 @@ extern "C" int svo_handle_create(int device, int max_keypoints, svo_handle** out
     h->device = device;
     h->stream = nullptr;
     h->max_kps = max_keypoints;
+    h->exact_pinv = 0;
     h->ring_cap = 1 << 20;
     h->ring_off = 0;
     HIP_TRY(hipMalloc(&h->ring, h->ring_cap));
@@ -93,6 +95,12 @@ extern "C" int svo_handle_destroy(svo_handle* h) {
 extern "C" int svo_handle_set_stream(svo_handle* h, void* s) {
     if (!h) return fail(SVO_ERR_INVALID, "null handle");
     h->stream = reinterpret_cast<hipStream_t>(s);
+    return SVO_OK;
+}
+
+extern "C" int svo_handle_set_exact_pinv(svo_handle* h, int on) {
+    if (!h) return fail(SVO_ERR_INVALID, "null handle");
+    h->exact_pinv = on != 0;
     return SVO_OK;
 }
 
@@ -200,6 +208,7 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     sa.cache = h->sia_cache; sa.kp_ws = h->sia_kpws;
     sa.dbg_H = dbg; sa.dbg_level = dbg_level;
     sa.cap = h->max_kps;
+    sa.exact_pinv = h->exact_pinv;
     SiaArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
@@ -256,6 +265,7 @@ extern "C" int svo_reproj_gn(svo_handle* h, svo_kp2d* kps2d, const svo_kp3d* kps
     ra.n_ptr = d_n;
     ra.kps2d = kps2d; ra.kps3d = kps3d; ra.flags = flags; ra.tracked = tracked; ra.err = err;
     ra.pose_in = pose_in; ra.pose_out = pose_out; ra.cost_out = cost; ra.trace = trace;
+    ra.exact_pinv = h->exact_pinv;
     ReprojArgs* d;
     rc = stage(h, ra, &d);
     if (rc) return rc;

@@ -204,6 +204,7 @@ struct svo_ctx {
     int* d_n_all = nullptr;      // [B*2]
     size_t sia_lds = 0;
     bool timing = false;
+    int exact_pinv = 0;
     hipEvent_t ev[10] = {nullptr};
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
@@ -470,6 +471,12 @@ extern "C" int svo_ctx_destroy(svo_ctx* c) {
     return SVO_OK;
 }
 
+extern "C" int svo_ctx_set_exact_pinv(svo_ctx* c, int on) {
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "null ctx");
+    c->exact_pinv = on != 0;
+    return SVO_OK;
+}
+
 extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
     if (!c) return svo_set_error(SVO_ERR_INVALID, "null ctx");
     c->timing = on != 0;
@@ -595,7 +602,7 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             sa->cam = c->cam; sa->n_ptr = k.n; sa->kps2d = k.kps2d; sa->kps3d = k.kps3d; sa->flags = k.flags;
             sa->pose_guess = d_guess; sa->pose_out = dr->pose_sia; sa->cost_out = &dr->sia_cost;
             sa->trace = dr->sia_trace; sa->cache = q.sia_cache; sa->kp_ws = q.sia_kpws;
-            sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap;
+            sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap; sa->exact_pinv = c->exact_pinv;
             KltArgs* ka = args_at<KltArgs>(c, c->off_klt, s);
             std::memset(ka, 0, sizeof(*ka));
             ka->kfs = q.d_kfs; ka->kf_id = k.kf_id; ka->n_cur = c->n_lk;
@@ -609,6 +616,7 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             ra->cam = c->cam; ra->n_ptr = k.n; ra->kps2d = k.kps2d; ra->kps3d = k.kps3d; ra->flags = k.flags;
             ra->tracked = q.tracked; ra->err = q.klt_err; ra->pose_in = dr->pose_sia;
             ra->pose_out = dr->pose_refined; ra->cost_out = &dr->reproj_cost; ra->trace = &dr->reproj_trace;
+            ra->exact_pinv = c->exact_pinv;
             SsdArgs* ss = args_at<SsdArgs>(c, c->off_ssd, s);
             std::memset(ss, 0, sizeof(*ss));
             ss->left = q.cur_set->left[0]; ss->right = q.cur_set->right; ss->n_ptr = k.n;

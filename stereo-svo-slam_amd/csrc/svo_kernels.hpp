@@ -38,6 +38,7 @@ struct SiaArgs {
     float* dbg_H;                 // optional [36+6+6]: H, b, step of the first get_gradient of `dbg_level`
     int dbg_level;
     int cap;
+    int exact_pinv;               // 1: always the reference's SVD pseudo-inverse (slow, parity mode)
 };
 void launch_sia(const SiaArgs* d_args, int batch, size_t lds_bytes, int cap, hipStream_t stream);
 size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap);
@@ -89,6 +90,7 @@ struct ReprojArgs {
     float* pose_out;
     float* cost_out;
     svo_gn_trace* trace;          // [1] or null
+    int exact_pinv;
 };
 void launch_reproj(const ReprojArgs* d_args, int batch, hipStream_t stream);
 

@@ -23,7 +23,7 @@ SYMBOLS = (
     "svo_ctx_create", "svo_ctx_destroy", "svo_new_images", "svo_new_image", "svo_get_pose",
     "svo_get_frame_keypoints", "svo_get_keyframe_count", "svo_get_keyframe",
     "svo_get_trajectory", "svo_update_pose", "svo_get_frame_stats", "svo_ctx_enable_timing",
-    "svo_get_totals",
+    "svo_get_totals", "svo_handle_set_exact_pinv", "svo_ctx_set_exact_pinv",
 )
 
 
@@ -114,6 +114,9 @@ class Handle:
 
     def synchronize(self):
         _check(lib().svo_handle_synchronize(self._h))
+
+    def set_exact_pinv(self, on=True):
+        _check(lib().svo_handle_set_exact_pinv(self._h, int(on)))
 
     def close(self):
         if getattr(self, "_h", None) and _LIB is not None:

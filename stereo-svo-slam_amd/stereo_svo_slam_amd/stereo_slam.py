@@ -81,6 +81,9 @@ class StereoSlamBatch:
         except Exception:
             pass
 
+    def set_exact_pinv(self, on=True):
+        _check(lib().svo_ctx_set_exact_pinv(self._ctx, int(on)))
+
     def enable_timing(self, on=True):
         _check(lib().svo_ctx_enable_timing(self._ctx, int(on)))
 

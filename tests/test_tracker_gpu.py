@@ -28,12 +28,13 @@ def _compare_frame(tag, gpu_frame, ok2, ok3, oinfo, pose_ref, tol=1e-4):
         assert np.max(np.abs(gpu_frame.kps3d - ok3)) < 5e-3, f"{tag}: kps3d"
 
 
-def _run(config, n_frames, seed, on_device=False, motion_scale=1.0):
+def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False):
     cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device="cpu",
                                                motion_scale=motion_scale)
     cam = util.oracle_camera(cfg)
     ref = O.Slam(cam)
-    gpu = StereoSlam(cfg)
+    gpu = StereoSlam(cfg, cfg["width"], cfg["height"])
+    gpu.set_exact_pinv(exact)
     n_kf = 0
     for k in range(n_frames):
         l, r = L[k].numpy(), R[k].numpy()
@@ -96,8 +97,9 @@ def test_first_frame_real_image():
 
 
 @pytest.mark.parametrize("config,n_frames,seed", [("tiny", 12, 0), ("tiny", 12, 3), ("euroc", 8, 0)])
-def test_sequence_matches_oracle(config, n_frames, seed):
-    _run(config, n_frames, seed)
+@pytest.mark.parametrize("exact", [False, True])
+def test_sequence_matches_oracle(config, n_frames, seed, exact):
+    _run(config, n_frames, seed, exact=exact)
 
 
 def test_sequence_with_keyframe_creation():
