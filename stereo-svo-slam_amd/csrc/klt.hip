@@ -9,16 +9,21 @@
 // in LDS with BORDER_REFLECT_101 addressing, the Scharr derivatives of
 // OpenCV's pyramid are computed from that tile (zero outside the image, as
 // the constant border of cv::buildOpticalFlowPyramid), and the fixed-point
-// template (14-bit weights, 5 fractional bits) stays in LDS for the
-// iterations. All window sums are exact integers reduced across the wave,
-// so the result does not depend on the reduction order.
+// template (14-bit weights, 5 fractional bits) stays in LDS. The search image
+// is staged once per level as a tile with a 6 px margin around the start
+// position, so an iteration touches HBM only when the window drifts out of
+// it. Lanes map to (row parity, column) of the window, so there is no
+// integer division in the loops; all window sums are exact integers reduced
+// with DPP row adds, so the result does not depend on the reduction order.
 #include "svo_kernels.hpp"
 
 namespace svo {
 
 constexpr int KLT_MAX_WIN = 35;
-constexpr int KLT_RW = KLT_MAX_WIN + 3;
-constexpr int KLT_DW = KLT_MAX_WIN + 1;
+constexpr int KLT_RW = KLT_MAX_WIN + 3;      // reference tile edge (window + 1 tap + 2 Scharr)
+constexpr int KLT_DW = KLT_MAX_WIN + 1;      // derivative / tap grid edge
+constexpr int KLT_MARGIN = 6;
+constexpr int KLT_TJ = KLT_DW + 2 * KLT_MARGIN;   // search tile edge
 
 #define SVO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
@@ -32,13 +37,18 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
     if (kp >= n) return;
     const int lane = threadIdx.x;
     const int win = a.win;
-    const int RW = win + 3, DW = win + 1;
+    const int RW = win + 3, DW = win + 1, TJ = DW + 2 * KLT_MARGIN;
+    // lane -> (row offset, column): two rows per step when a row fits in half a wave
+    const bool two = DW <= 32;
+    const int lc = two ? (lane & 31) : lane;
+    const int lr = two ? (lane >> 5) : 0;
+    const int rstep = two ? 2 : 1;
 
     __shared__ uint8_t s_I[KLT_RW * KLT_RW];
     __shared__ int s_d[KLT_DW * KLT_DW];          // packed (dx, dy) int16
     __shared__ short s_Iw[KLT_MAX_WIN * KLT_MAX_WIN];
     __shared__ int s_dIw[KLT_MAX_WIN * KLT_MAX_WIN];
-    __shared__ uint8_t s_J[KLT_DW * KLT_DW];
+    __shared__ uint8_t s_J[KLT_TJ * KLT_TJ];
 
     const int kfid = a.kf_id ? a.kf_id[kp] : 0;
     const KfDev& kf = a.kfs[kfid];
@@ -97,38 +107,41 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
 
         __syncthreads();
         // (w+3)^2 tile of I around the window, rows iprevy-1 .., reflect-101
-        for (int i = lane; i < RW * RW; i += 64) {
-            const int r = i / RW, c = i % RW;
-            const int gy = reflect101(iprevy - 1 + r, I.h), gx = reflect101(iprevx - 1 + c, I.w);
-            s_I[r * KLT_RW + c] = I.data[(size_t)gy * I.stride + gx];
+        if (lane < RW) {
+            const int gx = reflect101(iprevx - 1 + lane, I.w);
+            for (int r = 0; r < RW; r++) {
+                const int gy = reflect101(iprevy - 1 + r, I.h);
+                s_I[r * KLT_RW + lane] = I.data[(size_t)gy * I.stride + gx];
+            }
         }
         __syncthreads();
         // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions; 0 outside the image
-        for (int i = lane; i < DW * DW; i += 64) {
-            const int r = i / DW, c = i % DW;
-            const int gy = iprevy + r, gx = iprevx + c;
-            int packed = 0;
-            if ((unsigned)gy < (unsigned)I.h && (unsigned)gx < (unsigned)I.w) {
-                const uint8_t* p0 = &s_I[r * KLT_RW + c];       // row gy-1, col gx-1
-                const uint8_t* p1 = p0 + KLT_RW;
-                const uint8_t* p2 = p1 + KLT_RW;
-                const int t0m = (p0[0] + p2[0]) * 3 + p1[0] * 10, t0p = (p0[2] + p2[2]) * 3 + p1[2] * 10;
-                const int t1m = p2[0] - p0[0], t1c = p2[1] - p0[1], t1p = p2[2] - p0[2];
-                const int dx = t0p - t0m;
-                const int dy = (t1p + t1m) * 3 + t1c * 10;
-                packed = (dx & 0xffff) | (dy << 16);
+        if (lc < DW) {
+            const int gx = iprevx + lc;
+            const bool xin = (unsigned)gx < (unsigned)I.w;
+            for (int r = lr; r < DW; r += rstep) {
+                const int gy = iprevy + r;
+                int packed = 0;
+                if (xin && (unsigned)gy < (unsigned)I.h) {
+                    const uint8_t* p0 = &s_I[r * KLT_RW + lc];      // row gy-1, col gx-1
+                    const uint8_t* p1 = p0 + KLT_RW;
+                    const uint8_t* p2 = p1 + KLT_RW;
+                    const int t0m = (p0[0] + p2[0]) * 3 + p1[0] * 10, t0p = (p0[2] + p2[2]) * 3 + p1[2] * 10;
+                    const int t1m = p2[0] - p0[0], t1c = p2[1] - p0[1], t1p = p2[2] - p0[2];
+                    const int dx = t0p - t0m;
+                    const int dy = (t1p + t1m) * 3 + t1c * 10;
+                    packed = (dx & 0xffff) | (dy << 16);
+                }
+                s_d[r * KLT_DW + lc] = packed;
             }
-            s_d[r * KLT_DW + c] = packed;
         }
         __syncthreads();
-        // template + covariance of derivatives
-        long long iA11 = 0, iA12 = 0, iA22 = 0;
-        {
-            int a11 = 0, a12 = 0, a22 = 0, cnt = 0;
-            for (int i = lane; i < win * win; i += 64) {
-                const int y = i / win, x = i % win;
-                const uint8_t* src = &s_I[(y + 1) * KLT_RW + x + 1];
-                const int* ds = &s_d[y * KLT_DW + x];
+        // template + covariance of derivatives (per-lane int32 partials: <= 18 pixels each)
+        int a11 = 0, a12 = 0, a22 = 0;
+        if (lc < win) {
+            for (int y = lr; y < win; y += rstep) {
+                const uint8_t* src = &s_I[(y + 1) * KLT_RW + lc + 1];
+                const int* ds = &s_d[y * KLT_DW + lc];
                 const int ival = SVO_DESCALE(src[0] * iw00 + src[1] * iw01 + src[KLT_RW] * iw10 +
                                              src[KLT_RW + 1] * iw11, W_BITS - 5);
                 const int d00 = ds[0], d01 = ds[1], d10 = ds[KLT_DW], d11 = ds[KLT_DW + 1];
@@ -136,17 +149,13 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                                               (int)(short)d10 * iw10 + (int)(short)d11 * iw11, W_BITS);
                 const int iyval = SVO_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 +
                                               (d10 >> 16) * iw10 + (d11 >> 16) * iw11, W_BITS);
-                s_Iw[i] = (short)ival;
-                s_dIw[i] = (ixval & 0xffff) | (iyval << 16);
+                s_Iw[y * KLT_MAX_WIN + lc] = (short)ival;
+                s_dIw[y * KLT_MAX_WIN + lc] = (ixval & 0xffff) | (iyval << 16);
                 a11 += ixval * ixval; a12 += ixval * iyval; a22 += iyval * iyval;
-                if (++cnt == 16) {   // keep the per-lane partials inside int32
-                    iA11 += a11; iA12 += a12; iA22 += a22;
-                    a11 = a12 = a22 = 0; cnt = 0;
-                }
             }
-            iA11 += a11; iA12 += a12; iA22 += a22;
         }
-        iA11 = wave_sum_ll(iA11); iA12 = wave_sum_ll(iA12); iA22 = wave_sum_ll(iA22);
+        const long long iA11 = wave_sum_i32_to_i64(a11), iA12 = wave_sum_i32_to_i64(a12),
+                        iA22 = wave_sum_i32_to_i64(a22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE,
                     A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -159,6 +168,23 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
         D = 1.f / D;
         nextx -= halfWin; nexty -= halfWin;
         float prevDx = 0, prevDy = 0;
+        int tx0 = 0, ty0 = 0;
+        bool have_tile = false;
+
+        // stage the search tile [tx0, tx0+TJ) x [ty0, ty0+TJ) around (cx, cy)
+        auto load_tile = [&](int cx, int cy) {
+            tx0 = cx - KLT_MARGIN; ty0 = cy - KLT_MARGIN;
+            __syncthreads();
+            if (lane < TJ) {
+                const int gx = reflect101(tx0 + lane, J.w);
+                for (int r = 0; r < TJ; r++) {
+                    const int gy = reflect101(ty0 + r, J.h);
+                    s_J[r * KLT_TJ + lane] = J.data[(size_t)gy * J.stride + gx];
+                }
+            }
+            __syncthreads();
+            have_tile = true;
+        };
 
         for (int j = 0; j < 30; j++) {
             const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
@@ -166,37 +192,30 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                 if (level == 0) status = 0;
                 break;
             }
+            if (!have_tile || inextx < tx0 || inexty < ty0 || inextx + DW > tx0 + TJ || inexty + DW > ty0 + TJ)
+                load_tile(inextx, inexty);
             fa = nextx - inextx; fb = nexty - inexty;
             iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
             iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
             iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            __syncthreads();
-            for (int i = lane; i < DW * DW; i += 64) {
-                const int r = i / DW, c = i % DW;
-                const int gy = reflect101(inexty + r, J.h), gx = reflect101(inextx + c, J.w);
-                s_J[r * KLT_DW + c] = J.data[(size_t)gy * J.stride + gx];
-            }
-            __syncthreads();
-            long long ib1 = 0, ib2 = 0;
-            {
-                int b1 = 0, b2 = 0, cnt = 0;
-                for (int i = lane; i < win * win; i += 64) {
-                    const int y = i / win, x = i % win;
-                    const uint8_t* jp = &s_J[y * KLT_DW + x];
-                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_DW] * iw10 +
-                                                 jp[KLT_DW + 1] * iw11, W_BITS - 5) - (int)s_Iw[i];
-                    const int dI = s_dIw[i];
+            int b1 = 0, b2 = 0;
+            if (lc < win) {
+                const uint8_t* jbase = &s_J[(inexty - ty0) * KLT_TJ + (inextx - tx0) + lc];
+                for (int y = lr; y < win; y += rstep) {
+                    const uint8_t* jp = jbase + y * KLT_TJ;
+                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_TJ] * iw10 +
+                                                 jp[KLT_TJ + 1] * iw11, W_BITS - 5) -
+                                     (int)s_Iw[y * KLT_MAX_WIN + lc];
+                    const int dI = s_dIw[y * KLT_MAX_WIN + lc];
                     b1 += diff * (int)(short)dI;
                     b2 += diff * (dI >> 16);
-                    if (++cnt == 16) { ib1 += b1; ib2 += b2; b1 = b2 = 0; cnt = 0; }
                 }
-                ib1 += b1; ib2 += b2;
             }
-            ib1 = wave_sum_ll(ib1); ib2 = wave_sum_ll(ib2);
-            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
-            const float dx = (float)((A12 * b2 - A22 * b1) * D);
-            const float dy = (float)((A12 * b1 - A11 * b2) * D);
+            const long long ib1 = wave_sum_i32_to_i64(b1), ib2 = wave_sum_i32_to_i64(b2);
+            const float fb1 = (float)ib1 * FLT_SCALE, fb2 = (float)ib2 * FLT_SCALE;
+            const float dx = (float)((A12 * fb2 - A22 * fb1) * D);
+            const float dy = (float)((A12 * fb1 - A11 * fb2) * D);
             nextx += dx; nexty += dy;
             nx = nextx + halfWin; ny = nexty + halfWin;
             if ((double)dx * dx + (double)dy * dy <= epsilon) break;
@@ -214,27 +233,25 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                 status = 0;
                 continue;
             }
+            if (!have_tile || inx < tx0 || iny < ty0 || inx + DW > tx0 + TJ || iny + DW > ty0 + TJ)
+                load_tile(inx, iny);
             const float aa = npx - inx, bb = npy - iny;
             iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
             iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
             iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            __syncthreads();
-            for (int i = lane; i < DW * DW; i += 64) {
-                const int r = i / DW, c = i % DW;
-                const int gy = reflect101(iny + r, J.h), gx = reflect101(inx + c, J.w);
-                s_J[r * KLT_DW + c] = J.data[(size_t)gy * J.stride + gx];
-            }
-            __syncthreads();
             int e = 0;
-            for (int i = lane; i < win * win; i += 64) {
-                const int y = i / win, x = i % win;
-                const uint8_t* jp = &s_J[y * KLT_DW + x];
-                const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_DW] * iw10 +
-                                             jp[KLT_DW + 1] * iw11, W_BITS - 5) - (int)s_Iw[i];
-                e += diff < 0 ? -diff : diff;
+            if (lc < win) {
+                const uint8_t* jbase = &s_J[(iny - ty0) * KLT_TJ + (inx - tx0) + lc];
+                for (int y = lr; y < win; y += rstep) {
+                    const uint8_t* jp = jbase + y * KLT_TJ;
+                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_TJ] * iw10 +
+                                                 jp[KLT_TJ + 1] * iw11, W_BITS - 5) -
+                                     (int)s_Iw[y * KLT_MAX_WIN + lc];
+                    e += diff < 0 ? -diff : diff;
+                }
             }
-            e = wave_sum_i(e);   // < 2^24: the float sum of |diff| is exact in any order
+            e = wave_sum_dpp_i(e);   // < 2^24: the float sum of |diff| is exact in any order
             const float errval = (float)e;
             err = errval * 1.f / (32 * win * win);
         }

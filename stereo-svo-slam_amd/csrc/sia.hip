@@ -7,35 +7,49 @@
 // ONE persistent workgroup per sequence runs every pyramid level and every
 // Gauss-Newton / line-search iteration on the device (the reference makes up
 // to 50 cost evaluations per level; a launch per evaluation would cost more
-// than the whole CPU frame):
-//   * per level the current-frame level image is staged into LDS (it is
-//     23x15 .. 188x120 bytes at 752x480), so the 4x4 / 3x3 taps of every
-//     evaluation are LDS reads;
+// than the whole CPU frame). Per level:
+//   * both level images (previous and current frame; 23x15 .. 188x120 bytes at
+//     752x480) are staged into LDS, so every 4x4 / 3x3 tap is a ds_read;
 //   * everything that depends only on the previous frame — image gradients,
 //     reference patch sums, the reference half of the cost — is computed once
-//     per level into a 16-byte record per patch pixel (coalesced float4);
-//   * an evaluation = Rodrigues (lane 0) -> projection in double, one thread
-//     per keypoint -> 16 lanes per keypoint patch -> wave/LDS reduction of the
-//     cost or of the 21+6 normal-equation sums -> 6x6 pseudo-inverse,
-//     exponential map and the accept / halve / stop decision on lane 0.
-// Since the reference never caches its Hessian (the member is shadowed,
-// pose_estimator.cpp:399 vs :61) J^T J is rebuilt per get_gradient call; here
-// it is factored as sum_kp J_kp^T (sum_px g g^T) J_kp with the inner 2x2
-// constant per level.
+//     into per-patch-pixel records (LDS when they fit, else a workspace in HBM);
+//   * a cost evaluation = Rodrigues on lane 0 -> projection in double, one
+//     thread per keypoint -> 16 lanes per keypoint patch -> DPP row/wave
+//     reduction + one LDS pass;
+//   * get_gradient always follows a cost evaluation of the same pose, so it
+//     reuses that rotation and projection; the 21+6 normal-equation sums are
+//     built per keypoint as J^T (sum_px g g^T) J (the reference never caches
+//     its Hessian: the member is shadowed, pose_estimator.cpp:399 vs :61),
+//     reduced over the workgroup and solved on lane 0.
 #include "svo_kernels.hpp"
 #include "svo_reduce.hpp"
 
 namespace svo {
 
-constexpr int SIA_THREADS = 1024;
+#ifndef SVO_SIA_THREADS
+#define SVO_SIA_THREADS 512
+#endif
+constexpr int SIA_THREADS = SVO_SIA_THREADS;
+constexpr int SIA_WAVES = SIA_THREADS / 64;
 constexpr size_t SIA_LDS_BUDGET = 140 * 1024;
 
 struct SiaShared {
     PoseMats pm;
-    float red[SIA_THREADS / 64][32];
-    float sums[32];
+    float red[SIA_WAVES][28];
+    float sums[28];
     float grad[6];
+#ifdef SVO_SIA_STAMPS
+    long long stamp[12];   // diagnostic build only: cycles per phase, summed by thread 0
+#endif
 };
+
+#ifdef SVO_SIA_STAMPS
+#define SIA_STAMP(t) const long long t = __builtin_readcyclecounter()
+#define SIA_ACC(i, t1, t0) do { if (threadIdx.x == 0) sh.stamp[i] += (t1) - (t0); } while (0)
+#else
+#define SIA_STAMP(t)
+#define SIA_ACC(i, t1, t0)
+#endif
 
 // position of patch pixel (r, c) exactly as the reference's nested loops reach
 // it: x++ per column, x -= 4 and y++ at the end of a row (float arithmetic).
@@ -49,126 +63,222 @@ __device__ inline void patch_pos(float x0, float y0, int r, int c, float& x, flo
     for (int cc = 0; cc < c; cc++) x += 1.f;
 }
 
-struct LevelCtx {
-    const uint8_t* cur;     // LDS copy or global
-    int cur_stride, cur_w, cur_h;
-    ImgView prev;
-    float fx, fy, cx, cy;
-    int patch;              // window_size_pose_estimator
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// one level image: the LDS copy (LDS == true, row stride = w) or the HBM original
+template <bool LDS>
+struct LevelImg {
+    const uint8_t* p;
+    int w, h, stride;
+    __device__ inline int at(int y, int x) const { return (int)mem_ld<LDS>(p, y * stride + x); }
 };
 
-// do_calc: project + get_total_intensity_diff
-__device__ float sia_cost(const SiaArgs& a, int n, const LevelCtx& L, const float pose[6],
-                          SiaShared& sh, svo_kp2d* s_proj) {
+// get_patch_sum, src/lib/pose_estimator.cpp:82-112
+template <bool LDS>
+__device__ inline float patch_sum_img(const LevelImg<LDS>& im, float cx, float cy) {
+    const float sx = cx - 0.5f, sy = cy - 0.5f;
+    const int ipx = (int)floorf(sx), ipy = (int)floorf(sy);
+    const float x2 = sx - (float)ipx, y2 = sy - (float)ipy;
+    const float x1 = 1.0f - x2, y1 = 1.0f - y2;
+    const int o = ipy * im.stride + ipx;
+    const float a00 = (float)mem_ld<LDS>(im.p, o), a01 = (float)mem_ld<LDS>(im.p, o + 1),
+                a02 = (float)mem_ld<LDS>(im.p, o + 2);
+    const float a10 = (float)mem_ld<LDS>(im.p, o + im.stride), a11 = (float)mem_ld<LDS>(im.p, o + im.stride + 1),
+                a12 = (float)mem_ld<LDS>(im.p, o + im.stride + 2);
+    const float a20 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride), a21 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride + 1),
+                a22 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride + 2);
+    const float intensity = x1 * y1 * a00 + y1 * a01 + x2 * y1 * a02 +
+                            x1 * a10 + a11 + x2 * a12 +
+                            x1 * y2 * a20 + y2 * a21 + x2 * y2 * a22;
+    return intensity;
+}
+
+// per-level working set of the workgroup. LDS == true: images, records and the
+// per-keypoint arrays are in LDS; false: they stay in HBM (large configurations).
+template <bool LDS>
+struct LevelCtx {
+    LevelImg<LDS> cur, prev;
+    float fx, fy, cx, cy;
+    int patch;              // window_size_pose_estimator
+    // per patch pixel (n*16): reference cost sample, gradients, reference patch sum
+    float* rec_i1; float* rec_g0; float* rec_g1; float* rec_ps;
+    // per keypoint (cap): point + active flag, sum g g^T
+    v4f* kp_pt; v4f* kp_G;
+    v2f* proj;              // always LDS
+    float* slot;            // [64 groups][28]: J, (sum g g^T) J and the two residual sums of a patch (LDS)
+};
+
+__device__ inline float block_sum1(float v, SiaShared& sh) {
+    v = wave_sum_dpp(v);
     const int tid = threadIdx.x;
+    if ((tid & 63) == 0) sh.red[tid >> 6][0] = v;
     __syncthreads();
+    float s = sh.red[0][0];
+#pragma unroll
+    for (int w = 1; w < SIA_WAVES; w++) s += sh.red[w][0];
+    return s;   // same order in every thread
+}
+
+// do_calc: project + get_total_intensity_diff
+template <bool LDS>
+__device__ float sia_cost(const SiaArgs& a, int n, const LevelCtx<LDS>& L, const float pose[6], SiaShared& sh) {
+    const int tid = threadIdx.x;
+    SIA_STAMP(c0);
+    __syncthreads();                      // previous readers of pm / proj / red are done
+    SIA_STAMP(c1);
     if (tid == 0) pose_mats(pose, sh.pm);
+    SIA_STAMP(c2);
     __syncthreads();
     const CamD camd = make_camd(L.fx, L.fy, L.cx, L.cy, a.cam);
-    for (int i = tid; i < n; i += SIA_THREADS)
-        if (a.kp_ws[(size_t)i * 8 + 5] != 0.f)
-            s_proj[i] = project_point(sh.pm.Rd, sh.pm.t, camd, a.kps3d[i]);
+    for (int i = tid; i < n; i += SIA_THREADS) {
+        const v4f p = mem_ld<LDS>(L.kp_pt, i);
+        if (p.w != 0.f) {
+            const svo_kp2d q = project_point(sh.pm.Rd, sh.pm.t, camd, svo_kp3d{p.x, p.y, p.z});
+            mem_st<true>(L.proj, i, v2f{q.x, q.y});
+        }
+    }
+    SIA_STAMP(c3);
     __syncthreads();
-    float v[1] = {0};
+    SIA_STAMP(c4);
+    float v = 0;
     const int ps = L.patch;
+    const float half_size = ((float)ps - 1.0f) / 2.0f;
     for (int idx = tid; idx < n * 16; idx += SIA_THREADS) {
         const int kp = idx >> 4, px = idx & 15;
-        const float i1 = a.cache[idx].w;
+        const float i1 = mem_ld<LDS>(L.rec_i1, idx);
         if (i1 != i1) continue;                      // reference half invalid / inactive
-        const svo_kp2d q = s_proj[kp];
-        const float half_size = ((float)ps - 1.0f) / 2.0f;
+        const v2f q = mem_ld<true>(L.proj, kp);
         const float s2x = q.x - half_size, s2y = q.y - half_size;
         const float f2x = floorf(s2x), f2y = floorf(s2y);
         // keep absurd projections out of the int conversion
         if (!(f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f)) continue;
         const int ip2x = (int)f2x, ip2y = (int)f2y;
-        if (!(ip2y + ps < L.cur_h && ip2x + ps < L.cur_w)) continue;
+        if (!(ip2y + ps < L.cur.h && ip2x + ps < L.cur.w)) continue;
         const float x22 = s2x - (float)ip2x, y22 = s2y - (float)ip2y;
         const float x21 = 1.0f - x22, y21 = 1.0f - y22;
         const float m0 = x21 * y21, m1 = x22 * y21, m2 = x21 * y22, m3 = x22 * y22;
-        const int i = px >> 2, j = px & 3;
-        const uint8_t* p = L.cur + (long)(i + ip2y) * L.cur_stride + ip2x + j;
+        const int yy = (px >> 2) + ip2y, xx = (px & 3) + ip2x;
         float i2 = 0;
-        i2 += m0 * (float)p[0];
-        i2 += m1 * (float)p[1];
-        i2 += m2 * (float)p[L.cur_stride];
-        i2 += m3 * (float)p[L.cur_stride + 1];
-        v[0] += fabsf(i1 - i2);
+        i2 += m0 * (float)L.cur.at(yy, xx);
+        i2 += m1 * (float)L.cur.at(yy, xx + 1);
+        i2 += m2 * (float)L.cur.at(yy + 1, xx);
+        i2 += m3 * (float)L.cur.at(yy + 1, xx + 1);
+        v += fabsf(i1 - i2);
     }
-    block_reduce<1, SIA_THREADS>(v, sh.red, sh.sums);
-    return sh.sums[0];
+    SIA_STAMP(c5);
+    const float total = block_sum1(v, sh);
+    SIA_STAMP(c6);
+    SIA_ACC(0, c1, c0); SIA_ACC(1, c2, c1); SIA_ACC(2, c3, c2); SIA_ACC(3, c4, c3);
+    SIA_ACC(4, c5, c4); SIA_ACC(5, c6, c5); SIA_ACC(6, 1, 0);
+    return total;
 }
 
-// get_gradient (with calculate_hessian): leaves the 6-vector step in sh.grad
-__device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx& L, const float pose[6],
-                             SiaShared& sh, svo_kp2d* s_proj, float* dbg) {
+// (r, c) of the 21 upper-triangle entries of H in the order they are stored
+__constant__ int8_t c_tri_r[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__constant__ int8_t c_tri_c[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+
+// get_gradient (with calculate_hessian) at the pose of the LAST cost evaluation
+// (rotation in sh.pm and projections in L.proj are reused); leaves the step in sh.grad.
+// The 16 lanes of a patch first sum their residual*gradient terms (one DPP row),
+// lane 0 publishes J and (sum g g^T) J of the keypoint in an LDS slot, then every
+// lane owns two of the 27 outputs (21 entries of J^T G J, 6 of -J^T s).
+template <bool LDS>
+__device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, SiaShared& sh, float* dbg) {
     const int tid = threadIdx.x;
-    __syncthreads();
-    if (tid == 0) pose_mats(pose, sh.pm);
-    __syncthreads();
-    const CamD camd = make_camd(L.fx, L.fy, L.cx, L.cy, a.cam);
-    for (int i = tid; i < n; i += SIA_THREADS)
-        if (a.kp_ws[(size_t)i * 8 + 5] != 0.f)
-            s_proj[i] = project_point(sh.pm.Rd, sh.pm.t, camd, a.kps3d[i]);
-    __syncthreads();
-    float v[27];
-#pragma unroll
-    for (int k = 0; k < 27; k++) v[k] = 0;
-    const int npad = (n * 16 + 63) & ~63;            // whole waves take part in the shuffles
+    const int lane = tid & 63, wave = tid >> 6;
+    SIA_STAMP(g0);
+    float acc_a = 0, acc_b = 0;                      // outputs px and px + 16
+    const int px = tid & 15;
+    const int oa = px, ob = px + 16;
+    const int ra = c_tri_r[oa], ca = c_tri_c[oa];
+    const int rb = ob < 21 ? c_tri_r[ob] : ob - 21, cb = ob < 21 ? c_tri_c[ob] : 0;
+    float* slot = L.slot + (tid >> 4) * 28;
+    const int npad = (n * 16 + 63) & ~63;            // whole waves take part in the row sums
     for (int idx = tid; idx < npad; idx += SIA_THREADS) {
-        const int kp = idx >> 4, px = idx & 15;
+        const int kp = idx >> 4;
         float s0 = 0, s1 = 0;
         bool active = false;
+        v4f pt = {0, 0, 0, 0};
         if (idx < n * 16) {
-            active = a.kp_ws[(size_t)kp * 8 + 5] != 0.f;
-            const float4 rec = a.cache[idx];
-            if (active && rec.z == rec.z) {          // reference pixel inside (:449-451)
-                const svo_kp2d q = s_proj[kp];
+            pt = mem_ld<LDS>(L.kp_pt, kp);
+            active = pt.w != 0.f;
+            const float psr = mem_ld<LDS>(L.rec_ps, idx);
+            if (active && psr == psr) {              // reference pixel inside (:449-451)
+                const v2f q = mem_ld<true>(L.proj, kp);
                 float kx, ky;
                 patch_pos(q.x - 2.f, q.y - 2.f, px >> 2, px & 3, kx, ky);
                 if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
-                      ((double)kx + 2.0) > L.cur_w || ((double)ky + 2.0) > L.cur_h)) {
-                    const float d = patch_sum(L.cur, L.cur_stride, kx, ky) - rec.z;
-                    s0 = rec.x * d;
-                    s1 = rec.y * d;
+                      ((double)kx + 2.0) > L.cur.w || ((double)ky + 2.0) > L.cur.h)) {
+                    const float d = patch_sum_img(L.cur, kx, ky) - psr;
+                    s0 = mem_ld<LDS>(L.rec_g0, idx) * d;
+                    s1 = mem_ld<LDS>(L.rec_g1, idx) * d;
                 }
             }
         }
-        // sum over the 16 pixels of the patch (16 consecutive lanes)
+        s0 = row16_sum_dpp(s0);
+        s1 = row16_sum_dpp(s1);
+        if (px == 0) {
+            float J[12], M0[6], M1[6];
+            if (active) {
+                float X[3] = {pt.x - sh.pm.t[0], pt.y - sh.pm.t[1], pt.z - sh.pm.t[2]};
+                mat33f_vec(sh.pm.Ri, X, X);
+                pose_jacobian(L.fx, L.fy, X[0], X[1], X[2], J);
+                const v4f G = mem_ld<LDS>(L.kp_G, kp);
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) {
-            s0 += __shfl_xor(s0, o, 64);
-            s1 += __shfl_xor(s1, o, 64);
-        }
-        if (px == 0 && active) {
-            const svo_kp3d P = a.kps3d[kp];
-            float X[3] = {P.x - sh.pm.t[0], P.y - sh.pm.t[1], P.z - sh.pm.t[2]};
-            mat33f_vec(sh.pm.Ri, X, X);
-            float J[12];
-            pose_jacobian(L.fx, L.fy, X[0], X[1], X[2], J);
-            const float gxx = a.kp_ws[(size_t)kp * 8 + 0], gxy = a.kp_ws[(size_t)kp * 8 + 1],
-                        gyy = a.kp_ws[(size_t)kp * 8 + 2];
-            float M0[6], M1[6];                      // (sum g g^T) J
+                for (int k = 0; k < 6; k++) {            // (sum g g^T) J
+                    M0[k] = G.x * J[k] + G.y * J[6 + k];
+                    M1[k] = G.y * J[k] + G.z * J[6 + k];
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
-                M0[k] = gxx * J[k] + gxy * J[6 + k];
-                M1[k] = gxy * J[k] + gyy * J[6 + k];
+                for (int k = 0; k < 12; k++) J[k] = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { M0[k] = 0; M1[k] = 0; }
             }
-            int q = 0;
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 12; k++) mem_st<true>(slot, k, J[k]);
 #pragma unroll
-                for (int c = r; c < 6; c++) v[q++] += J[r] * M0[c] + J[6 + r] * M1[c];
-#pragma unroll
-            for (int k = 0; k < 6; k++) v[21 + k] -= J[k] * s0 + J[6 + k] * s1;
+            for (int k = 0; k < 6; k++) { mem_st<true>(slot, 12 + k, M0[k]); mem_st<true>(slot, 18 + k, M1[k]); }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // H entry (ra, ca) and either H entry (rb, cb) or b entry rb
+        acc_a += mem_ld<true>(slot, ra) * mem_ld<true>(slot, 12 + ca) +
+                 mem_ld<true>(slot, 6 + ra) * mem_ld<true>(slot, 18 + ca);
+        if (ob < 21)
+            acc_b += mem_ld<true>(slot, rb) * mem_ld<true>(slot, 12 + cb) +
+                     mem_ld<true>(slot, 6 + rb) * mem_ld<true>(slot, 18 + cb);
+        else if (ob < 27)
+            acc_b -= mem_ld<true>(slot, rb) * s0 + mem_ld<true>(slot, 6 + rb) * s1;
+        __builtin_amdgcn_wave_barrier();                 // slot is rewritten in the next pass
     }
-    block_reduce<27, SIA_THREADS>(v, sh.red, sh.sums);
+    // the four patches of a wave, then the waves
+    acc_a += __shfl_xor(acc_a, 16, 64); acc_a += __shfl_xor(acc_a, 32, 64);
+    acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
+    if (lane < 16) {
+        sh.red[wave][oa] = acc_a;
+        if (ob < 27) sh.red[wave][ob] = acc_b;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        float s = sh.red[0][tid];
+#pragma unroll
+        for (int w = 1; w < SIA_WAVES; w++) s += sh.red[w][tid];
+        sh.sums[tid] = s;
+    }
+    __syncthreads();
+    SIA_STAMP(g1);
+    SIA_ACC(7, g1, g0);
     if (tid == 0) {
         float H[36], b[6], delta[6], pg[6];
         int q = 0;
+#pragma unroll
         for (int r = 0; r < 6; r++)
+#pragma unroll
             for (int c = r; c < 6; c++) { H[r * 6 + c] = sh.sums[q]; H[c * 6 + r] = sh.sums[q]; q++; }
+#pragma unroll
         for (int r = 0; r < 6; r++) b[r] = sh.sums[21 + r];
         gn_solve6(H, b, delta, a.exact_pinv != 0);
         exponential_map(delta, pg);
@@ -179,20 +289,72 @@ __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx& L, const f
             for (int k = 0; k < 6; k++) { dbg[36 + k] = b[k]; dbg[42 + k] = sh.grad[k]; }
         }
     }
+    SIA_STAMP(g2);
+    SIA_ACC(8, g2, g1); SIA_ACC(9, 1, 0);
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __restrict__ args,
-                                                              unsigned lds_img_bytes) {
-    const SiaArgs& a = args[blockIdx.x];
-    const int n = min(*a.n_ptr, a.cap);
+// LDS carve-up (host and device must agree). "fits": per-keypoint arrays and both
+// copies of the largest level image are in LDS and `rec_floats` floats are left
+// for the records (16 B per patch pixel); otherwise only the projections are.
+struct SiaLds {
+    size_t proj, slot, kp_pt, kp_G, img_cur, img_prev, rec, total;
+    int fits, img_bytes, rec_floats;
+};
+
+__host__ __device__ inline SiaLds sia_lds_layout(int cap, int max_img_bytes) {
+    SiaLds l;
+    size_t off = 0;
+    l.proj = off; off += ((size_t)cap * sizeof(svo_kp2d) + 15) & ~(size_t)15;
+    l.slot = off; off += (size_t)(SIA_THREADS / 16) * 28 * 4;
+    const size_t img = ((size_t)max_img_bytes + 15) & ~(size_t)15;
+    const size_t want = off + (size_t)cap * 32 + 2 * img;
+    l.fits = (max_img_bytes > 0 && want + 64 * 256 <= SIA_LDS_BUDGET) ? 1 : 0;   // room for >= 64 patches
+    l.kp_pt = l.kp_G = l.img_cur = l.img_prev = l.rec = off;
+    l.img_bytes = 0; l.rec_floats = 0;
+    if (l.fits) {
+        l.kp_pt = off; off += (size_t)cap * 16;
+        l.kp_G = off; off += (size_t)cap * 16;
+        l.img_bytes = (int)img;
+        l.img_cur = off; off += img;
+        l.img_prev = off; off += img;
+        l.rec = off;
+        l.rec_floats = (int)((SIA_LDS_BUDGET - off) / 4);
+        off = SIA_LDS_BUDGET;
+    }
+    l.total = off;
+    return l;
+}
+
+template <bool LDS>
+__device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, const SiaLds& lay) {
     const int tid = threadIdx.x;
-    __shared__ SiaShared sh;
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    svo_kp2d* s_proj = reinterpret_cast<svo_kp2d*>(dyn);
-    uint8_t* s_img = dyn + (((size_t)a.cap * sizeof(svo_kp2d) + 15) & ~(size_t)15);
+    LevelCtx<LDS> L;
+    L.proj = reinterpret_cast<v2f*>(dyn + lay.proj);
+    L.slot = reinterpret_cast<float*>(dyn + lay.slot);
+    if (LDS) {
+        L.kp_pt = reinterpret_cast<v4f*>(dyn + lay.kp_pt);
+        L.kp_G = reinterpret_cast<v4f*>(dyn + lay.kp_G);
+        float* r = reinterpret_cast<float*>(dyn + lay.rec);
+        L.rec_i1 = r; L.rec_g0 = r + n * 16; L.rec_g1 = r + 2 * n * 16; L.rec_ps = r + 3 * n * 16;
+    } else {
+        L.kp_pt = reinterpret_cast<v4f*>(a.kp_ws);
+        L.kp_G = reinterpret_cast<v4f*>(a.kp_ws) + a.cap;
+        float* r = reinterpret_cast<float*>(a.cache);
+        const size_t c16 = (size_t)a.cap * 16;
+        L.rec_i1 = r; L.rec_g0 = r + c16; L.rec_g1 = r + 2 * c16; L.rec_ps = r + 3 * c16;
+    }
+    L.patch = a.cam.window_size_pose_estimator;
+
+    // active set and points (PoseEstimatorCallback ctor, :238-245)
+    for (int i = tid; i < n; i += SIA_THREADS) {
+        const svo_kp3d P = a.kps3d[i];
+        const bool active = !(a.flags && (a.flags[i] & SVO_IGNORE_TEMPORARY));
+        mem_st<LDS>(L.kp_pt, i, v4f{P.x, P.y, P.z, active ? 1.f : 0.f});
+    }
 
     float est[6];
+#pragma unroll
     for (int j = 0; j < 6; j++) est[j] = a.pose_guess[j];
     float last_cost = 0;
     bool dbg_done = false;
@@ -200,23 +362,28 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
     for (int lv = a.cam.max_pyramid_levels; lv > a.cam.min_pyramid_level_pose_estimation; lv--) {
         const int level = lv - 1;
         const int divider = 1 << level;
-        LevelCtx L;
-        L.prev = a.prev[level];
-        const ImgView cur = a.cur[level];
+        const ImgView cur = a.cur[level], prev = a.prev[level];
         L.fx = a.cam.fx / divider; L.fy = a.cam.fy / divider;
         L.cx = a.cam.cx / divider; L.cy = a.cam.cy / divider;
-        L.patch = a.cam.window_size_pose_estimator;
-        L.cur_w = cur.w; L.cur_h = cur.h;
-        __syncthreads();
-        if ((size_t)cur.w * cur.h <= lds_img_bytes) {
+        __syncthreads();                 // everybody is done with the previous level's LDS
+        if (LDS) {
+            uint8_t* sc = dyn + lay.img_cur;
+            uint8_t* sp = dyn + lay.img_prev;
             for (int i = tid; i < cur.w * cur.h; i += SIA_THREADS) {
                 const int r = i / cur.w, c = i - r * cur.w;
-                s_img[i] = cur.data[(size_t)r * cur.stride + c];
+                mem_st<true>(sc, i, cur.data[(size_t)r * cur.stride + c]);
             }
-            L.cur = s_img; L.cur_stride = cur.w;
+            for (int i = tid; i < prev.w * prev.h; i += SIA_THREADS) {
+                const int r = i / prev.w, c = i - r * prev.w;
+                mem_st<true>(sp, i, prev.data[(size_t)r * prev.stride + c]);
+            }
+            L.cur = LevelImg<LDS>{sc, cur.w, cur.h, cur.w};
+            L.prev = LevelImg<LDS>{sp, prev.w, prev.h, prev.w};
         } else {
-            L.cur = cur.data; L.cur_stride = cur.stride;
+            L.cur = LevelImg<LDS>{cur.data, cur.w, cur.h, cur.stride};
+            L.prev = LevelImg<LDS>{prev.data, prev.w, prev.h, prev.stride};
         }
+        __syncthreads();
 
         // ---- per-level records that depend on the previous frame only
         const int npad = (n * 16 + 63) & ~63;
@@ -226,7 +393,7 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
             bool active = false;
             svo_kp2d kref = {0, 0};
             if (idx < n * 16) {
-                active = !(a.flags && (a.flags[kp] & SVO_IGNORE_TEMPORARY));   // ctor, :238-245
+                active = mem_ld<LDS>(L.kp_pt, kp).w != 0.f;
                 kref = a.kps2d[kp];
                 if (level != 0) { kref.x /= divider; kref.y /= divider; }      // setLevel
             }
@@ -236,16 +403,16 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
                 // calculate_hessian bounds (:351-352)
                 if (!(((double)kx - 2.0) < 0 || ((double)ky - 2.0) < 0 ||
                       ((double)kx + 3.0) >= L.prev.w || ((double)ky + 3.0) >= L.prev.h)) {
-                    const float int1 = patch_sum(L.prev.data, L.prev.stride, kx + 1, ky);
-                    const float int2 = patch_sum(L.prev.data, L.prev.stride, kx - 1, ky);
-                    const float int3 = patch_sum(L.prev.data, L.prev.stride, kx, ky + 1);
-                    const float int4 = patch_sum(L.prev.data, L.prev.stride, kx, ky - 1);
+                    const float int1 = patch_sum_img(L.prev, kx + 1, ky);
+                    const float int2 = patch_sum_img(L.prev, kx - 1, ky);
+                    const float int3 = patch_sum_img(L.prev, kx, ky + 1);
+                    const float int4 = patch_sum_img(L.prev, kx, ky - 1);
                     g0 = int1 - int2; g1 = int3 - int4;
                 }
                 // reference half of the residual test (:449-453)
                 if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
                       ((double)kx + 2.0) > L.prev.w || ((double)ky + 2.0) > L.prev.h))
-                    psr = patch_sum(L.prev.data, L.prev.stride, kx, ky);
+                    psr = patch_sum_img(L.prev, kx, ky);
                 // reference half of the cost (image_comparison.cpp:20-88)
                 const int ps = L.patch;
                 const float half_size = ((float)ps - 1.0f) / 2.0f;
@@ -257,54 +424,53 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
                         const float x12 = s1x - (float)ip1x, y12 = s1y - (float)ip1y;
                         const float x11 = 1.0f - x12, y11 = 1.0f - y12;
                         const float m0 = x11 * y11, m1 = x12 * y11, m2 = x11 * y12, m3 = x12 * y12;
-                        const int i = px >> 2, j = px & 3;
-                        const uint8_t* p = L.prev.data + (size_t)(i + ip1y) * L.prev.stride + ip1x + j;
+                        const int yy = (px >> 2) + ip1y, xx = (px & 3) + ip1x;
                         float t = 0;
-                        t += m0 * (float)p[0];
-                        t += m1 * (float)p[1];
-                        t += m2 * (float)p[L.prev.stride];
-                        t += m3 * (float)p[L.prev.stride + 1];
+                        t += m0 * (float)L.prev.at(yy, xx);
+                        t += m1 * (float)L.prev.at(yy, xx + 1);
+                        t += m2 * (float)L.prev.at(yy + 1, xx);
+                        t += m3 * (float)L.prev.at(yy + 1, xx + 1);
                         i1 = t;
                     }
                 }
             }
-            if (idx < n * 16) a.cache[idx] = make_float4(g0, g1, psr, i1);
-            float gxx = g0 * g0, gxy = g0 * g1, gyy = g1 * g1;
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) {
-                gxx += __shfl_xor(gxx, o, 64);
-                gxy += __shfl_xor(gxy, o, 64);
-                gyy += __shfl_xor(gyy, o, 64);
+            if (idx < n * 16) {
+                mem_st<LDS>(L.rec_i1, idx, i1); mem_st<LDS>(L.rec_g0, idx, g0);
+                mem_st<LDS>(L.rec_g1, idx, g1); mem_st<LDS>(L.rec_ps, idx, psr);
             }
-            if (px == 0 && idx < n * 16) {
-                float* w = a.kp_ws + (size_t)kp * 8;
-                w[0] = gxx; w[1] = gxy; w[2] = gyy; w[3] = kref.x; w[4] = kref.y;
-                w[5] = active ? 1.f : 0.f;
-            }
+            const float gxx = row16_sum_dpp(g0 * g0), gxy = row16_sum_dpp(g0 * g1),
+                        gyy = row16_sum_dpp(g1 * g1);
+            if (px == 0 && idx < n * 16) mem_st<LDS>(L.kp_G, kp, v4f{gxx, gxy, gyy, 0.f});
         }
         __syncthreads();
 
-        // ---- estimate_pose_at_level (:166-222); i is shared by both loops
+        // ---- estimate_pose_at_level (:166-222); i is shared by both loops.
+        // Every get_gradient(x0) directly follows the cost evaluation of x0 (the
+        // initial one or the accepted trial), so it reuses that rotation/projection.
         const int maxIter = 50;
         float x0[6];
+#pragma unroll
         for (int j = 0; j < 6; j++) x0[j] = est[j];
         int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0;
-        float prev_cost = sia_cost(a, n, L, x0, sh, s_proj);
+        float prev_cost = sia_cost<LDS>(a, n, L, x0, sh);
         const float initial = prev_cost;
         for (int i = 0; i < maxIter; i++) {
             float* dbg = (a.dbg_H && !dbg_done && level == a.dbg_level) ? a.dbg_H : nullptr;
-            sia_gradient(a, n, L, x0, sh, s_proj, dbg);
+            sia_gradient<LDS>(a, n, L, sh, dbg);
             if (dbg) dbg_done = true;
             n_grad++;
             float g[6];
+#pragma unroll
             for (int j = 0; j < 6; j++) g[j] = sh.grad[j];
             float k = 1.0f;
             for (; i < maxIter; i++) {
                 float x[6];
+#pragma unroll
                 for (int j = 0; j < 6; j++) x[j] = x0[j] + k * g[j];
-                const float new_cost = sia_cost(a, n, L, x, sh, s_proj);
+                const float new_cost = sia_cost<LDS>(a, n, L, x, sh);
                 n_cost++;
                 if (new_cost < prev_cost) {
+#pragma unroll
                     for (int j = 0; j < 6; j++) x0[j] = x[j];
                     prev_cost = new_cost;
                     accepted++;
@@ -317,6 +483,7 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
                     k /= 2;
             }
         }
+#pragma unroll
         for (int j = 0; j < 6; j++) est[j] = x0[j];
         last_cost = prev_cost;
         if (tid == 0 && a.trace) {
@@ -333,28 +500,55 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
     }
 }
 
-size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
-    const size_t proj = ((size_t)cap * sizeof(svo_kp2d) + 15) & ~(size_t)15;
-    size_t img = 0;
-    for (int lv = cam.max_pyramid_levels; lv > cam.min_pyramid_level_pose_estimation; lv--) {
-        const int level = lv - 1;
-        const size_t b = (size_t)(width >> level) * (size_t)(height >> level);
-        if (proj + b <= SIA_LDS_BUDGET && b > img) img = b;
+__global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __restrict__ args,
+                                                              int max_img_bytes) {
+    const SiaArgs& a = args[blockIdx.x];
+    const int n = min(*a.n_ptr, a.cap);
+    __shared__ SiaShared sh;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+    const SiaLds lay = sia_lds_layout(a.cap, max_img_bytes);
+#ifdef SVO_SIA_STAMPS
+    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) sh.stamp[i] = 0;
+    const long long k0 = __builtin_readcyclecounter();
+#endif
+    // everything in LDS when this frame's patches fit, else the HBM workspace
+    if (lay.fits && (size_t)n * 64 <= (size_t)lay.rec_floats) sia_run<true>(a, n, sh, dyn, lay);
+    else sia_run<false>(a, n, sh, dyn, lay);
+#ifdef SVO_SIA_STAMPS
+    if (threadIdx.x == 0 && a.dbg_H) {   // diagnostic build: the debug buffer carries cycle counts
+        sh.stamp[10] = __builtin_readcyclecounter() - k0;
+        for (int i = 0; i < 12; i++) a.dbg_H[i] = (float)sh.stamp[i];
     }
-    return proj + img;
+#endif
 }
 
-void launch_sia(const SiaArgs* d_args, int batch, size_t lds_bytes, int cap, hipStream_t stream) {
+static int sia_max_img_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
+    // the largest level (of those the estimator uses) whose two copies still fit
+    int best = 0;
+    for (int lv = cam.max_pyramid_levels; lv > cam.min_pyramid_level_pose_estimation; lv--) {
+        const int level = lv - 1;
+        const int b = (width >> level) * (height >> level);
+        const SiaLds l = sia_lds_layout(cap, b);
+        if (l.fits && b > best) best = b;
+    }
+    return best;
+}
+
+size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
+    return sia_lds_layout(cap, sia_max_img_bytes(cam, width, height, cap)).total;
+}
+
+void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+                int height, int cap, hipStream_t stream) {
     static size_t configured = 0;
+    const int img = sia_max_img_bytes(cam, width, height, cap);
+    const size_t lds_bytes = sia_lds_layout(cap, img).total;
     if (lds_bytes > configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         configured = lds_bytes;
     }
-    const size_t proj = ((size_t)cap * sizeof(svo_kp2d) + 15) & ~(size_t)15;
-    const unsigned img_bytes = (unsigned)(lds_bytes > proj ? lds_bytes - proj : 0);
-    hipLaunchKernelGGL(sia_gn_kernel, dim3(batch), dim3(SIA_THREADS), lds_bytes, stream, d_args,
-                       img_bytes);
+    hipLaunchKernelGGL(sia_gn_kernel, dim3(batch), dim3(SIA_THREADS), lds_bytes, stream, d_args, img);
 }
 
 }  // namespace svo

@@ -655,7 +655,7 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         SVO_MARK(1);
         launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
         SVO_MARK(2);
-        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->sia_lds, c->cap, c->stream);
+        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, c->cap, c->stream);
         SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, c->cap, c->cam.window_size_opt_flow, c->stream);
         SVO_MARK(4);

@@ -24,6 +24,21 @@ __host__ __device__ inline ImgView make_view(const svo_image& im) {
     return ImgView{im.data, im.width, im.height, im.stride};
 }
 
+// ------------------------------------------------------ address-space typed access
+// A generic pointer that is known to point into LDS: cast to address space 3 so
+// the compiler emits ds_read/ds_write instead of flat instructions.
+#define SVO_LDS(T) __attribute__((address_space(3))) T
+template <bool LDS, typename T>
+__device__ inline T mem_ld(const T* p, int i) {
+    if constexpr (LDS) return ((const SVO_LDS(T)*)p)[i];
+    else return p[i];
+}
+template <bool LDS, typename T>
+__device__ inline void mem_st(T* p, int i, const T& v) {
+    if constexpr (LDS) ((SVO_LDS(T)*)p)[i] = v;
+    else p[i] = v;
+}
+
 // ---------------------------------------------------------------- wave ops
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -39,6 +54,54 @@ __device__ inline long long wave_sum_ll(long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// DPP (data-parallel primitive) cross-lane adds: no LDS crossbar, ~1 VALU op each.
+// A DPP row is 16 lanes; controls: quad_perm(1,0,3,2)=0xB1, quad_perm(2,3,0,1)=0x4E,
+// row_half_mirror=0x141, row_mirror=0x140.
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ inline int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+// sum over each group of 16 consecutive lanes, result in all 16 lanes (fixed order)
+__device__ inline float row16_sum_dpp(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return v;
+}
+__device__ inline int row16_sum_dpp_i(int v) {
+    v += dpp_i<0xB1>(v);
+    v += dpp_i<0x4E>(v);
+    v += dpp_i<0x141>(v);
+    v += dpp_i<0x140>(v);
+    return v;
+}
+// sum over the 64 lanes of the wave, same value (and same rounding) in every lane
+__device__ inline float wave_sum_dpp(float v) {
+    v = row16_sum_dpp(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+__device__ inline int wave_sum_dpp_i(int v) {
+    v = row16_sum_dpp_i(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+// exact 64-bit sum of per-lane int32 partials (|v| < 2^31): low 16 bits and the
+// signed high part are reduced separately in int32 and recombined
+__device__ inline long long wave_sum_i32_to_i64(int v) {
+    const int lo = wave_sum_dpp_i(v & 0xFFFF);
+    const int hi = wave_sum_dpp_i(v >> 16);
+    return (long long)hi * 65536LL + (long long)lo;
 }
 
 // ------------------------------------------------------------- rotations
@@ -150,14 +213,19 @@ __device__ inline void exponential_map(const float twist[6], float out[6]) {
     const float K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     float K2[9], M[9];
     const float norm = 1.0f;
-    const double c1 = 1 - cos((double)norm);
-    const double c2 = norm - sin((double)norm);
+    // 1 - cos(1.0) and 1.0 - sin(1.0) in double (the device math library would not fold them)
+    const double c1 = 0x1.d6bafe095f2e8p-2;
+    const double c2 = 0x1.44aadc3dbcc48p-3;
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             float s = 0;
+#pragma unroll
             for (int k = 0; k < 3; k++) s += K[i * 3 + k] * K[k * 3 + j];
             K2[i * 3 + j] = s;
         }
+#pragma unroll
     for (int k = 0; k < 9; k++) {
         const float e = (k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f;
         const float t0 = e * norm;
@@ -248,7 +316,7 @@ __host__ __device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], flo
 
 // Matx66f::inv(DECOMP_SVD): zeros when sigma_max < FLT_EPSILON or
 // sigma_min / sigma_max == 0, else V diag(1/w) U^T with the SVBkSb threshold.
-__device__ inline void inv_svd6(const float H[36], float Hinv[36]) {
+__device__ __attribute__((noinline)) void inv_svd6(const float H[36], float Hinv[36]) {
     float At[6][6], Vt[6][6], W[6];
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) At[i][j] = H[j * 6 + i];
@@ -284,30 +352,40 @@ __device__ inline void gn_solve6(const float H[36], const float b[6], float delt
     bool ok = !exact;
     if (ok) {
         double L[6][6], D[6], dmax = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++) dmax = fmax(dmax, (double)H[i * 6 + i]);
         const double tiny = dmax * 1e-6;
-        for (int j = 0; j < 6 && ok; j++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
             double d = H[j * 6 + j];
+#pragma unroll
             for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
-            if (!(d > tiny) || !(dmax > 0)) { ok = false; break; }
+            if (!(d > tiny) || !(dmax > 0)) ok = false;
             D[j] = d;
             const double id = 1.0 / d;
+#pragma unroll
             for (int i = j + 1; i < 6; i++) {
                 double v = H[i * 6 + j];
+#pragma unroll
                 for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
                 L[i][j] = v * id;
             }
         }
         if (ok) {
             double z[6];
+#pragma unroll
             for (int i = 0; i < 6; i++) {
                 double v = b[i];
+#pragma unroll
                 for (int k = 0; k < i; k++) v -= L[i][k] * z[k];
                 z[i] = v;
             }
+#pragma unroll
             for (int i = 0; i < 6; i++) z[i] /= D[i];
+#pragma unroll
             for (int i = 5; i >= 0; i--) {
                 double v = z[i];
+#pragma unroll
                 for (int k = i + 1; k < 6; k++) v -= L[k][i] * z[k];
                 z[i] = v;
                 delta[i] = (float)v;

@@ -40,7 +40,8 @@ struct SiaArgs {
     int cap;
     int exact_pinv;               // 1: always the reference's SVD pseudo-inverse (slow, parity mode)
 };
-void launch_sia(const SiaArgs* d_args, int batch, size_t lds_bytes, int cap, hipStream_t stream);
+void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+                int height, int cap, hipStream_t stream);
 size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap);
 
 // --------------------------------------------------------------------- KLT

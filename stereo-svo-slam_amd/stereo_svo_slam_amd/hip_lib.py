@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "libsvo_hip.so")
+LIB_PATH = os.environ.get("SVO_HIP_LIB", os.path.join(CSRC, "libsvo_hip.so"))   # override: diagnostic builds
 _LIB = None
 
 # every symbol include/svo_hip.h declares
