@@ -66,14 +66,13 @@ def render_sequences(cfg_name, seq_ids, n_frames, device):
         gen = torch.Generator(device=device)
         gen.manual_seed(1234 + sid)
         ls, rs = [], []
-        for k in range(n_frames):
-            l = sc.render(cfg, poses[k], False, 0.0)
-            r = sc.render(cfg, poses[k], True, 0.0)
-            # sensor noise, sigma = 1 grey level
-            l = (l.float() + torch.randn(l.shape, device=device, generator=gen)).round().clamp(0, 255).to(torch.uint8)
-            r = (r.float() + torch.randn(r.shape, device=device, generator=gen)).round().clamp(0, 255).to(torch.uint8)
-            ls.append(l.contiguous())
-            rs.append(r.contiguous())
+        for k0 in range(0, n_frames, 16):                     # 16 frames per ray-cast batch
+            pk = poses[k0:k0 + 16]
+            for out, right in ((ls, False), (rs, True)):
+                im = sc.render_batch(cfg, pk, right)
+                # sensor noise, sigma = 1 grey level
+                im = (im + torch.randn(im.shape, device=device, generator=gen)).round().clamp(0, 255).to(torch.uint8)
+                out.extend(im[i].contiguous() for i in range(im.shape[0]))
         lefts.append(ls)
         rights.append(rs)
     return cfg, lefts, rights, ts

@@ -460,6 +460,15 @@ void svo_oi_lkpyr_free(svo_oi_lkpyr *p)
 
 #define LK_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+/* diagnostics: LK iterations executed since the last reset (not part of any result) */
+static long long g_lk_iterations = 0, g_lk_points = 0;
+long long svo_o_lk_iterations(int reset)
+{
+    long long v = g_lk_iterations;
+    if (reset) { g_lk_iterations = 0; g_lk_points = 0; }
+    return v;
+}
+
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
@@ -549,6 +558,7 @@ void svo_oi_klt_track(const svo_oi_lkpyr *P, const svo_oi_lkpyr *N, const svo_kp
             float prevDx = 0, prevDy = 0;
 
             for (int j = 0; j < maxCount; j++) {
+                g_lk_iterations++;
                 const int inextx = cv_floor_f(nextx), inexty = cv_floor_f(nexty);
                 if (inextx < -win || inextx >= Jcols || inexty < -win || inexty >= Jrows) {
                     if (level == 0) status[ptidx] = 0;

@@ -109,9 +109,16 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
         // (w+3)^2 tile of I around the window, rows iprevy-1 .., reflect-101
         if (lane < RW) {
             const int gx = reflect101(iprevx - 1 + lane, I.w);
-            for (int r = 0; r < RW; r++) {
-                const int gy = reflect101(iprevy - 1 + r, I.h);
-                s_I[r * KLT_RW + lane] = I.data[(size_t)gy * I.stride + gx];
+            for (int r0 = 0; r0 < RW; r0 += 8) {       // 8 independent loads in flight
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int gy = reflect101(iprevy - 1 + min(r0 + u, RW - 1), I.h);
+                    v[u] = I.data[(size_t)gy * I.stride + gx];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (r0 + u < RW) s_I[(r0 + u) * KLT_RW + lane] = v[u];
             }
         }
         __syncthreads();
@@ -177,9 +184,16 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
             __syncthreads();
             if (lane < TJ) {
                 const int gx = reflect101(tx0 + lane, J.w);
-                for (int r = 0; r < TJ; r++) {
-                    const int gy = reflect101(ty0 + r, J.h);
-                    s_J[r * KLT_TJ + lane] = J.data[(size_t)gy * J.stride + gx];
+                for (int r0 = 0; r0 < TJ; r0 += 8) {
+                    uint8_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int gy = reflect101(ty0 + min(r0 + u, TJ - 1), J.h);
+                        v[u] = J.data[(size_t)gy * J.stride + gx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (r0 + u < TJ) s_J[(r0 + u) * KLT_TJ + lane] = v[u];
                 }
             }
             __syncthreads();

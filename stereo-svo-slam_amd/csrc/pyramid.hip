@@ -17,32 +17,58 @@ namespace svo {
 // ------------------------------------------------------------------ P1
 constexpr int HS_TILE = 64;  // level-0 tile edge; yields levels up to 6 (1x1)
 
-__global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __restrict__ args) {
+// 16 bytes of row `gy` starting at column gx (0 beyond the row end)
+__device__ inline uint4 load_row16(const ImgView& im, int gy, int gx) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gy < im.h && gx < im.w) {
+        const uint8_t* p = im.data + (size_t)gy * im.stride + gx;
+        if (gx + 16 <= im.w && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+            v = *reinterpret_cast<const uint4*>(p);
+        } else {
+            uint8_t b[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[i] = (gx + i < im.w) ? p[i] : 0;
+            v = *reinterpret_cast<const uint4*>(b);
+        }
+    }
+    return v;
+}
+__device__ inline void store_row16(const ImgView& im, int gy, int gx, uint4 v) {
+    if (gy >= im.h || gx >= im.w) return;
+    uint8_t* q = const_cast<uint8_t*>(im.data) + (size_t)gy * im.stride + gx;
+    if (gx + 16 <= im.w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
+        *reinterpret_cast<uint4*>(q) = v;
+    } else {
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (gx + i < im.w) q[i] = b[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __restrict__ args, int batch) {
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * HS_TILE, y0 = blockIdx.y * HS_TILE;
+    if ((int)blockIdx.z >= batch) {
+        // ingest of the right image: plain tile copy (createImgPyramid(right, 1), stereo_slam.cpp:136)
+        const PyrArgs& b = args[blockIdx.z - batch];
+        const int r = tid >> 2, c = (tid & 3) * 16;
+        store_row16(b.dst_right, y0 + r, x0 + c, load_row16(b.src_right, y0 + r, x0 + c));
+        return;
+    }
     const PyrArgs& a = args[blockIdx.z];
     __shared__ uint8_t t0[HS_TILE * HS_TILE];
     __shared__ uint8_t t1[32 * 32];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * HS_TILE, y0 = blockIdx.y * HS_TILE;
-    const ImgView src = a.level[0];
+    const bool ingest = a.src_left.data != nullptr;
+    const ImgView src = ingest ? a.src_left : a.level[0];
     if (x0 >= src.w || y0 >= src.h) return;
 
     // stage the level-0 tile: 4 threads x 16 B per row, 64 rows
     {
         const int r = tid >> 2, c = (tid & 3) * 16;
-        const int gy = y0 + r, gx = x0 + c;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy < src.h) {
-            const uint8_t* p = src.data + (size_t)gy * src.stride + gx;
-            if (gx + 16 <= src.w && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                v = *reinterpret_cast<const uint4*>(p);
-            } else {
-                uint8_t b[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) b[i] = (gx + i < src.w) ? p[i] : 0;
-                v = *reinterpret_cast<const uint4*>(b);
-            }
-        }
+        const uint4 v = load_row16(src, y0 + r, x0 + c);
         *reinterpret_cast<uint4*>(&t0[r * HS_TILE + c]) = v;
+        if (ingest) store_row16(a.level[0], y0 + r, x0 + c, v);   // resident copy of level 0
     }
     __syncthreads();
 
@@ -130,9 +156,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrArgs* __restrict
     }
 }
 
-void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, hipStream_t stream) {
-    dim3 grid((w + HS_TILE - 1) / HS_TILE, (h + HS_TILE - 1) / HS_TILE, batch);
-    hipLaunchKernelGGL(pyr_halfsample_kernel, grid, dim3(256), 0, stream, d_args);
+void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, bool ingest, hipStream_t stream) {
+    dim3 grid((w + HS_TILE - 1) / HS_TILE, (h + HS_TILE - 1) / HS_TILE, ingest ? 2 * batch : batch);
+    hipLaunchKernelGGL(pyr_halfsample_kernel, grid, dim3(256), 0, stream, d_args, batch);
 }
 
 void launch_pyr_down(const PyrArgs* d_args, int batch, int src_level, int dst_w, int dst_h,

@@ -149,7 +149,7 @@ extern "C" int svo_build_pyramid(svo_handle* h, int n_levels, svo_image* levels)
     PyrArgs* d;
     int rc = stage(h, pa, &d);
     if (rc) return rc;
-    if (n_levels > 1) launch_pyr_halfsample(d, 1, levels[0].width, levels[0].height, h->stream);
+    if (n_levels > 1) launch_pyr_halfsample(d, 1, levels[0].width, levels[0].height, false, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

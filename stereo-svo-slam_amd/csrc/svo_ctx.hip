@@ -565,14 +565,22 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         q.prev_set = q.cur_set;
         if ((rc = acquire_set(c, q, &q.cur_set))) return rc;
         ImageSet* is = q.cur_set;
-        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->left[0].data), is->left[0].stride, left[s],
-                                 stride, c->width, c->height, kind, c->stream));
-        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->right.data), is->right.stride, right[s],
-                                 stride, c->width, c->height, kind, c->stream));
         PyrArgs* hs = args_at<PyrArgs>(c, c->off_hs, s);
         std::memset(hs, 0, sizeof(*hs));
         hs->n_levels = c->cam.max_pyramid_levels;
         for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
+        if (mem == SVO_MEM_DEVICE) {
+            // device-resident frames are ingested by the pyramid kernel itself (one launch
+            // for all sequences instead of 2 copies per sequence)
+            hs->src_left = ImgView{left[s], c->width, c->height, stride};
+            hs->src_right = ImgView{right[s], c->width, c->height, stride};
+            hs->dst_right = is->right;
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->left[0].data), is->left[0].stride, left[s],
+                                     stride, c->width, c->height, kind, c->stream));
+            HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->right.data), is->right.stride, right[s],
+                                     stride, c->width, c->height, kind, c->stream));
+        }
         PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, s);
         std::memset(lk, 0, sizeof(*lk));
         lk->n_levels = c->n_lk;
@@ -635,7 +643,8 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         }
     }
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
-    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height, c->stream);
+    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height,
+                          mem == SVO_MEM_DEVICE, c->stream);
     {
         int w = c->width, h = c->height;
         for (int l = 0; l + 1 < c->n_lk; l++) {

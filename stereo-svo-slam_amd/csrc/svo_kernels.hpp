@@ -13,10 +13,14 @@ namespace svo {
 
 // ---------------------------------------------------------------- pyramids
 struct PyrArgs {
-    ImgView level[SVO_MAX_PYRAMID_LEVELS];  // [0] = input, [1..] = outputs
+    ImgView level[SVO_MAX_PYRAMID_LEVELS];  // [0] = input (or its resident copy), [1..] = outputs
     int n_levels;
+    // optional ingest of device-resident caller images (svo_new_images, SVO_MEM_DEVICE):
+    // level[0] is then WRITTEN from src_left while the pyramid is built, and the
+    // right image is copied by the blocks with blockIdx.z >= batch.
+    ImgView src_left, src_right, dst_right;
 };
-void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, hipStream_t stream);
+void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, bool ingest, hipStream_t stream);
 void launch_pyr_down(const PyrArgs* d_args, int batch, int src_level, int dst_w, int dst_h,
                      hipStream_t stream);
 

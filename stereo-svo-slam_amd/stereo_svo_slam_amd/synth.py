@@ -125,50 +125,60 @@ class Scene:
                 hu=float(hu), hv=float(hv), tex=tex,
                 off=(float(rng.uniform(0, 1024)), float(rng.uniform(0, 1024)))))
 
-    def render(self, cfg, pose, right=False, noise_sigma=1.0, noise_seed=None):
-        """uint8 (height, width) image of the camera at `pose` (6 floats)."""
+    def render_batch(self, cfg, poses, right=False):
+        """float32 [K, height, width] noise-free images of the camera at poses [K, 6]."""
         dev = self.device
         w, h = cfg["width"], cfg["height"]
-        pose = np.asarray(pose, np.float64)
-        R = torch.tensor(rodrigues(pose[3:6]), dtype=torch.float64, device=dev)
-        o = torch.tensor(pose[0:3], dtype=torch.float64, device=dev)
+        poses = np.asarray(poses, np.float64).reshape(-1, 6)
+        K = poses.shape[0]
+        R = torch.tensor(np.stack([rodrigues(p[3:6]) for p in poses]), dtype=torch.float64, device=dev)
+        o = torch.tensor(poses[:, 0:3], dtype=torch.float64, device=dev)
         if right:
             b = cfg["baseline"] / cfg["fx"]
-            o = o + R @ torch.tensor([-b, 0.0, 0.0], dtype=torch.float64, device=dev)
+            o = o + (R @ torch.tensor([-b, 0.0, 0.0], dtype=torch.float64, device=dev))
         xs = (torch.arange(w, dtype=torch.float64, device=dev) - cfg["cx"]) / cfg["fx"]
         ys = (torch.arange(h, dtype=torch.float64, device=dev) - cfg["cy"]) / cfg["fy"]
         dc = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w),
                           torch.ones(h, w, dtype=torch.float64, device=dev)], -1)
-        d = dc @ R.T                                            # world ray directions
-        best_s = torch.full((h, w), float("inf"), dtype=torch.float64, device=dev)
-        img = torch.zeros(h, w, dtype=torch.float32, device=dev)
+        d = torch.einsum("hwc,kdc->khwd", dc, R)                  # world ray directions [K,h,w,3]
+        best_s = torch.full((K, h, w), float("inf"), dtype=torch.float64, device=dev)
+        img = torch.zeros(K, h, w, dtype=torch.float32, device=dev)
         for pl in self.planes:
             n = torch.linalg.cross(pl["u"], pl["v"])
             dn = d @ n
-            s = ((pl["p0"] - o) @ n) / dn
-            q = o + s[..., None] * d - pl["p0"]
+            s = ((pl["p0"] - o) @ n)[:, None, None] / dn
+            q = o[:, None, None, :] + s[..., None] * d - pl["p0"]
             tu, tv = q @ pl["u"], q @ pl["v"]
+            del q
             ok = (s > 1e-3) & (s < best_s) & torch.isfinite(s)
             if pl["hu"] > 0:
                 ok &= (tu.abs() < pl["hu"]) & (tv.abs() < pl["hv"])
             fu = tu * self.tpm + pl["off"][0]
             fv = tv * self.tpm + pl["off"][1]
+            del tu, tv
             iu, iv = torch.floor(fu), torch.floor(fv)
             au, av = (fu - iu).float(), (fv - iv).float()
             size = pl["tex"].shape[0]
             iu0 = torch.remainder(iu, size).long()
             iv0 = torch.remainder(iv, size).long()
+            del fu, fv, iu, iv
+            zero = torch.zeros_like(iu0)
+            iu0 = torch.where(ok, iu0, zero)
+            iv0 = torch.where(ok, iv0, zero)
             iu1 = torch.remainder(iu0 + 1, size)
             iv1 = torch.remainder(iv0 + 1, size)
-            iu0 = torch.where(ok, iu0, torch.zeros_like(iu0))
-            iv0 = torch.where(ok, iv0, torch.zeros_like(iv0))
-            iu1 = torch.where(ok, iu1, torch.zeros_like(iu1))
-            iv1 = torch.where(ok, iv1, torch.zeros_like(iv1))
             t = pl["tex"]
             val = (t[iv0, iu0] * (1 - au) * (1 - av) + t[iv0, iu1] * au * (1 - av) +
                    t[iv1, iu0] * (1 - au) * av + t[iv1, iu1] * au * av)
             img = torch.where(ok, val, img)
             best_s = torch.where(ok, s, best_s)
+        return img
+
+    def render(self, cfg, pose, right=False, noise_sigma=1.0, noise_seed=None):
+        """uint8 (height, width) image of the camera at `pose` (6 floats)."""
+        dev = self.device
+        w, h = cfg["width"], cfg["height"]
+        img = self.render_batch(cfg, np.asarray(pose, np.float64)[None], right)[0]
         if noise_sigma > 0:
             if noise_seed is None:
                 img = img + noise_sigma * torch.randn(h, w, device=dev)
