@@ -110,12 +110,14 @@ def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
     ap.add_argument("--seqs", type=int, default=64, help="sequences per GPU (share every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--single", action="store_true",
+                    help="also time one sequence alone (latency leg; off by default so that a "
+                         "rocprofv3 --stats run of the default command sees only the batched launches)")
     args = ap.parse_args()
 
     rank, local_rank, world = multi_seq.init_distributed()
@@ -175,7 +177,7 @@ def main():
                 "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
 
     single = None
-    if not args.no_single:
+    if args.single:
         one = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1, device.index)
         one.enable_timing(True)
         sia_ms, n_grad = 0.0, 0

@@ -15,22 +15,120 @@
 
 namespace svo {
 
-constexpr int SSD_MAX_WIN = 36;                 // template edge (window <= 35)
-constexpr int SSD_TW4 = 9;                      // dwords per template row
-constexpr int SSD_T_STRIDE = 12;                // dwords (48 B: three aligned 16 B reads)
-constexpr int SSD_T_ROWS = SSD_MAX_WIN + 6;     // 3 zero rows before and after
-constexpr int SSD_R_STRIDE = 112;               // bytes per search-region row (>= 35+64+pad)
-constexpr int SSD_R_ROWS = SSD_MAX_WIN + 16 + 4;
-constexpr int SSD_MAX_MATCH = 65 * 17;
+// 4 consecutive pixels of row y starting at column x as one (possibly unaligned)
+// dword load, cut to `valid` bytes; byte loads only where the dword would run
+// past the end of the image row
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ inline uint32_t load_u8x4(const ImgView& im, int y, int x, int valid) {
+    const uint8_t* src = im.data + (size_t)y * im.stride + x;
+    uint32_t v;
+    if (x + 4 <= im.w) {
+        v = *reinterpret_cast<const u32_unaligned*>(src);
+    } else {
+        v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (x + b < im.w) v |= (uint32_t)src[b] << (8 * b);
+    }
+    if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+    return v;
+}
 
-// C1. One workgroup per keypoint. The template (zero padded to whole dwords)
-// and the search region sit in LDS. A work item is 4 vertically adjacent
-// offsets (k0..k0+3, j): every search-region row is read once (10 dwords,
-// funnel-shifted to the column phase j&3 with v_alignbyte), squared once
-// (v_dot4_u32_u8 with itself) and multiplied against the 4 template rows it
-// meets (v_dot4_u32_u8), so SSD = sum a^2 - 2 sum a*t + sum t^2 costs ~0.7
-// instructions per pixel pair and stays an exact integer.
-__global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
+constexpr int SSD_MAX_WIN = 36;                 // template edge (window <= 35)
+constexpr int SSD_NOFF = 4;                     // vertically adjacent offsets per work item
+constexpr int SSD_T_STRIDE = 12;                // dwords (48 B: aligned 16 B reads)
+constexpr int SSD_T_PAD = SSD_NOFF - 1;         // zero rows before the template
+constexpr int SSD_T_ROWS = SSD_MAX_WIN + 2 * SSD_T_PAD + 4;
+constexpr int SSD_R_STRIDE = 112;               // bytes per search-region row (>= 35+64+pad)
+constexpr int SSD_R_ROWS = SSD_MAX_WIN + 16 + SSD_NOFF + 4;
+constexpr int SSD_MAX_MATCH = 65 * 17;
+constexpr int SSD_THREADS = 256;
+
+// C1. One workgroup per keypoint. The template (zero padded to whole dwords,
+// with zero rows above and below) and the search region sit in LDS. A work
+// item is 4 vertically adjacent offsets (k0..k0+3, j): every search-region row
+// is read once (TW4+1 dwords, funnel-shifted to the column phase j&3 with
+// v_alignbyte), squared once (v_dot4_u32_u8 with itself) and multiplied
+// against the 4 template rows it meets (v_dot4_u32_u8); the template rows
+// slide through registers (one broadcast LDS read per step), so
+// SSD = sum a^2 - 2 sum a*t + sum t^2 costs ~0.4 instructions per pixel pair
+// and stays an exact integer. TW4 = dwords per template row (6, 8 or 9).
+template <int TW4>
+__device__ inline void ssd_load_trow(const uint32_t* s_t, int row, uint32_t (&t)[TW4]) {
+    const uint4* t4 = reinterpret_cast<const uint4*>(&s_t[(row + SSD_T_PAD) * SSD_T_STRIDE]);
+    uint32_t tv[12];
+    *reinterpret_cast<uint4*>(&tv[0]) = t4[0];
+    if (TW4 > 4) *reinterpret_cast<uint4*>(&tv[4]) = t4[1];
+    if (TW4 > 8) *reinterpret_cast<uint4*>(&tv[8]) = t4[2];
+#pragma unroll
+    for (int d = 0; d < TW4; d++) t[d] = tv[d];
+}
+
+template <int TW4, bool ANYW>
+__device__ inline void ssd_items(const uint32_t* s_t, const uint8_t* s_r, int* s_m, uint32_t stt,
+                                 int tw, int th, int mw, int mh) {
+    const int tid = threadIdx.x;
+    // !ANYW: tw fills exactly TW4 dwords, only the last one is partial.
+    // ANYW (windows clamped at the image border): a mask per dword.
+    const int rem = tw - 4 * (TW4 - 1);
+    const uint32_t last_mask = (rem >= 4 || rem <= 0) ? 0xFFFFFFFFu : ((1u << (8 * rem)) - 1u);
+    uint32_t msk[TW4];
+#pragma unroll
+    for (int d = 0; d < TW4; d++) {
+        const int rd = tw - 4 * d;
+        msk[d] = rd >= 4 ? 0xFFFFFFFFu : (rd <= 0 ? 0u : ((1u << (8 * rd)) - 1u));
+    }
+    const int ngroups = (mh + SSD_NOFF - 1) / SSD_NOFF;
+    const int nsteps = (th + SSD_NOFF - 1 + 3) & ~3;           // whole rotations of the 4 row registers
+    for (int item = tid; item < ngroups * mw; item += SSD_THREADS) {
+        const int kg = item / mw, j = item - kg * mw;
+        const int k0 = kg * SSD_NOFF;
+        const unsigned shift = (unsigned)(j & 3);
+        const uint32_t* rbase = reinterpret_cast<const uint32_t*>(s_r) + (j >> 2) + k0 * (SSD_R_STRIDE / 4);
+        uint32_t sab0 = 0, sab1 = 0, sab2 = 0, sab3 = 0, saa0 = 0, saa1 = 0, saa2 = 0, saa3 = 0;
+        uint32_t ta[TW4], tb[TW4], tc[TW4], td[TW4];            // template rows st, st-1, st-2, st-3
+#pragma unroll
+        for (int d = 0; d < TW4; d++) { ta[d] = 0; tb[d] = 0; tc[d] = 0; td[d] = 0; }
+
+        // one search-region row against the template rows (t0 newest .. t3 oldest)
+        auto step = [&](int st, uint32_t (&t0)[TW4], const uint32_t (&t1)[TW4],
+                        const uint32_t (&t2)[TW4], const uint32_t (&t3)[TW4]) {
+            ssd_load_trow<TW4>(s_t, st, t0);
+            const uint32_t* rr = rbase + st * (SSD_R_STRIDE / 4);
+            uint32_t w[TW4 + 1];
+#pragma unroll
+            for (int d = 0; d <= TW4; d++) w[d] = rr[d];
+            uint32_t rowsq = 0;
+#pragma unroll
+            for (int d = 0; d < TW4; d++) {
+                uint32_t v = __builtin_amdgcn_alignbyte(w[d + 1], w[d], shift);   // column phase j & 3
+                if (ANYW) v &= msk[d];
+                else if (d == TW4 - 1) v &= last_mask;
+                rowsq = __builtin_amdgcn_udot4(v, v, rowsq, false);
+                sab0 = __builtin_amdgcn_udot4(v, t0[d], sab0, false);
+                sab1 = __builtin_amdgcn_udot4(v, t1[d], sab1, false);
+                sab2 = __builtin_amdgcn_udot4(v, t2[d], sab2, false);
+                sab3 = __builtin_amdgcn_udot4(v, t3[d], sab3, false);
+            }
+            saa0 += (st < th) ? rowsq : 0u;
+            saa1 += (st >= 1 && st - 1 < th) ? rowsq : 0u;
+            saa2 += (st >= 2 && st - 2 < th) ? rowsq : 0u;
+            saa3 += (st >= 3 && st - 3 < th) ? rowsq : 0u;
+        };
+        for (int st = 0; st < nsteps; st += 4) {
+            step(st, ta, tb, tc, td);
+            step(st + 1, td, ta, tb, tc);
+            step(st + 2, tc, td, ta, tb);
+            step(st + 3, tb, tc, td, ta);
+        }
+        if (k0 + 0 < mh) s_m[(k0 + 0) * mw + j] = (int)(saa0 + stt - 2u * sab0);
+        if (k0 + 1 < mh) s_m[(k0 + 1) * mw + j] = (int)(saa1 + stt - 2u * sab1);
+        if (k0 + 2 < mh) s_m[(k0 + 2) * mw + j] = (int)(saa2 + stt - 2u * sab2);
+        if (k0 + 3 < mh) s_m[(k0 + 3) * mw + j] = (int)(saa3 + stt - 2u * sab3);
+    }
+}
+
+__global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
     const SsdArgs& a = args[blockIdx.y];
     if (a.enable && !*a.enable) return;
     const int n = *a.n_ptr;
@@ -42,8 +140,8 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     __shared__ __attribute__((aligned(16))) uint8_t s_r[SSD_R_ROWS * SSD_R_STRIDE];
     __shared__ int s_m[SSD_MAX_MATCH];
     __shared__ uint32_t s_tt[SSD_MAX_WIN];
-    __shared__ unsigned long long s_key[4];
-    __shared__ int s_sum[4], s_cnt[4];
+    __shared__ unsigned long long s_key[SSD_THREADS / 64];
+    __shared__ int s_sum[SSD_THREADS / 64], s_cnt[SSD_THREADS / 64];
 
     const int window_before = a.win / 2, window_after = (a.win + 1) / 2;
     const int cols = a.left.w, rows = a.left.h;
@@ -63,7 +161,7 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     if (a.clamp_half && (x12 <= 0 || y12 <= 0 || x11 >= cols - 1 || y11 >= rows - 1)) skip = true;
     if (a.clamp_half && (x22 <= 0 || y22 <= 0 || x21 >= cols - 1 || y21 >= rows - 1)) skip = true;
     if (tw <= 0 || th <= 0 || mw <= 0 || mh <= 0) skip = true;
-    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || rw > SSD_R_STRIDE - 12 || rh > SSD_R_ROWS - 4 ||
+    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || rw > SSD_R_STRIDE - 12 || rh > SSD_R_ROWS - SSD_NOFF - 4 ||
         mw * mh > SSD_MAX_MATCH)
         skip = true;  // the host validates window sizes; never taken with valid settings
     if (skip) {
@@ -71,35 +169,27 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
         return;
     }
 
-    // ---- stage template (rows -3..th+2, zero outside) and search region (zero outside)
-    for (int i = tid; i < SSD_T_ROWS * SSD_T_STRIDE; i += 256) {
-        const int r = i / SSD_T_STRIDE - 3, d = i % SSD_T_STRIDE;
+    // ---- stage template (zero rows around it, zero beyond tw) and search region (zero outside)
+    for (int i = tid; i < SSD_T_ROWS * SSD_T_STRIDE; i += SSD_THREADS) {
+        const int r = i / SSD_T_STRIDE - SSD_T_PAD, d = i % SSD_T_STRIDE;
         uint32_t v = 0;
-        if (r >= 0 && r < th) {
-            const uint8_t* src = a.left.data + (size_t)(y11 + r) * a.left.stride + x11 + 4 * d;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (4 * d + b < tw) v |= (uint32_t)src[b] << (8 * b);
-        }
+        if (r >= 0 && r < th && 4 * d < tw)
+            v = load_u8x4(a.left, y11 + r, x11 + 4 * d, tw - 4 * d);
         s_t[i] = v;
     }
-    for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 4); i += 256) {
+    for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 4); i += SSD_THREADS) {
         const int r = i / (SSD_R_STRIDE / 4), d = i % (SSD_R_STRIDE / 4);
         uint32_t v = 0;
-        if (r < rh) {
-            const uint8_t* src = a.right.data + (size_t)(y21 + r) * a.right.stride + x21 + 4 * d;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (4 * d + b < rw) v |= (uint32_t)src[b] << (8 * b);
-        }
+        if (r < rh && 4 * d < rw)
+            v = load_u8x4(a.right, y21 + r, x21 + 4 * d, rw - 4 * d);
         reinterpret_cast<uint32_t*>(s_r)[i] = v;
     }
     __syncthreads();
     if (tid < th) {
         uint32_t tt = 0;
 #pragma unroll
-        for (int d = 0; d < SSD_TW4; d++) {
-            const uint32_t t = s_t[(tid + 3) * SSD_T_STRIDE + d];
+        for (int d = 0; d < 9; d++) {
+            const uint32_t t = s_t[(tid + SSD_T_PAD) * SSD_T_STRIDE + d];
             tt = __builtin_amdgcn_udot4(t, t, tt, false);
         }
         s_tt[tid] = tt;
@@ -108,64 +198,16 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     uint32_t stt = 0;
     for (int r = 0; r < th; r++) stt += s_tt[r];
 
-    // masks that cut the search-region dwords to the template width
-    uint32_t msk[SSD_TW4];
-#pragma unroll
-    for (int d = 0; d < SSD_TW4; d++) {
-        const int rem = tw - 4 * d;
-        msk[d] = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
-    }
-
-    const int ngroups = (mh + 3) >> 2;
-    for (int item = tid; item < ngroups * mw; item += 256) {
-        const int kg = item / mw, j = item - kg * mw;
-        const int k0 = kg * 4;
-        const unsigned shift = (unsigned)(j & 3);
-        const uint32_t* rbase = reinterpret_cast<const uint32_t*>(s_r) + (j >> 2);
-        uint32_t sab0 = 0, sab1 = 0, sab2 = 0, sab3 = 0;
-        uint32_t saa0 = 0, saa1 = 0, saa2 = 0, saa3 = 0;
-        for (int st = 0; st < th + 3; st++) {
-            const uint32_t* rr = rbase + (k0 + st) * (SSD_R_STRIDE / 4);
-            uint32_t w[SSD_TW4 + 1];
-#pragma unroll
-            for (int d = 0; d <= SSD_TW4; d++) w[d] = rr[d];
-            uint32_t av[SSD_TW4];
-            uint32_t rowsq = 0;
-#pragma unroll
-            for (int d = 0; d < SSD_TW4; d++) {
-                // funnel shift by the column phase j & 3 (bytes)
-                uint32_t v = __builtin_amdgcn_alignbyte(w[d + 1], w[d], shift);
-                v &= msk[d];
-                av[d] = v;
-                rowsq = __builtin_amdgcn_udot4(v, v, rowsq, false);
-            }
-            // this region row meets template row st - i for offset k0 + i
-            const uint32_t* t0 = &s_t[(st + 3) * SSD_T_STRIDE];
-            const uint32_t* t1 = t0 - SSD_T_STRIDE;
-            const uint32_t* t2 = t1 - SSD_T_STRIDE;
-            const uint32_t* t3 = t2 - SSD_T_STRIDE;
-#pragma unroll
-            for (int d = 0; d < SSD_TW4; d++) {
-                sab0 = __builtin_amdgcn_udot4(av[d], t0[d], sab0, false);
-                sab1 = __builtin_amdgcn_udot4(av[d], t1[d], sab1, false);
-                sab2 = __builtin_amdgcn_udot4(av[d], t2[d], sab2, false);
-                sab3 = __builtin_amdgcn_udot4(av[d], t3[d], sab3, false);
-            }
-            saa0 += (st < th) ? rowsq : 0u;
-            saa1 += (st >= 1 && st - 1 < th) ? rowsq : 0u;
-            saa2 += (st >= 2 && st - 2 < th) ? rowsq : 0u;
-            saa3 += (st >= 3) ? rowsq : 0u;
-        }
-        if (k0 + 0 < mh) s_m[(k0 + 0) * mw + j] = (int)(saa0 + stt - 2u * sab0);
-        if (k0 + 1 < mh) s_m[(k0 + 1) * mw + j] = (int)(saa1 + stt - 2u * sab1);
-        if (k0 + 2 < mh) s_m[(k0 + 2) * mw + j] = (int)(saa2 + stt - 2u * sab2);
-        if (k0 + 3 < mh) s_m[(k0 + 3) * mw + j] = (int)(saa3 + stt - 2u * sab3);
-    }
+    const int tw4 = (tw + 3) >> 2;
+    if (tw4 == 8) ssd_items<8, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);        // window 29..32
+    else if (tw4 == 9) ssd_items<9, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);   // window 33..36
+    else if (tw4 == 6) ssd_items<6, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);   // window 21..24
+    else ssd_items<9, true>(s_t, s_r, s_m, stt, tw, th, mw, mh);                  // anything else
     __syncthreads();
 
     const int nm = mw * mh;
     unsigned long long best = ~0ull;
-    for (int o = tid; o < nm; o += 256) {
+    for (int o = tid; o < nm; o += SSD_THREADS) {
         const unsigned long long key = ((unsigned long long)(unsigned)s_m[o] << 32) | (unsigned)o;
         best = key < best ? key : best;
     }
@@ -178,24 +220,24 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
     if ((tid & 63) == 0) s_key[tid >> 6] = best;
     __syncthreads();
     best = s_key[0];
-    for (int w = 1; w < 4; w++) best = s_key[w] < best ? s_key[w] : best;
+    for (int w = 1; w < SSD_THREADS / 64; w++) best = s_key[w] < best ? s_key[w] : best;
     const int min_int = (int)(best >> 32);
     const int min_o = (int)(best & 0xffffffffu);
     const int minx = min_o % mw, miny = min_o / mw;
     const float minVal = (float)min_int;
 
     int sumj = 0, cnt = 0;
-    for (int o = tid; o < nm; o += 256) {
+    for (int o = tid; o < nm; o += SSD_THREADS) {
         const int k = o / mw, j = o % mw;
         if (j >= minx && k >= miny && (double)(float)s_m[o] <= (double)minVal) { sumj += j; cnt++; }
     }
-    sumj = wave_sum_i(sumj);
-    cnt = wave_sum_i(cnt);
+    sumj = wave_sum_dpp_i(sumj);
+    cnt = wave_sum_dpp_i(cnt);
     if ((tid & 63) == 0) { s_sum[tid >> 6] = sumj; s_cnt[tid >> 6] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        const int ts = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int ts = 0, tc = 0;
+        for (int w = 0; w < SSD_THREADS / 64; w++) { ts += s_sum[w]; tc += s_cnt[w]; }
         float minPos = (float)ts;      // sum of small ints: exact in float in any order
         minPos = minPos / tc;
         a.disparity[kp] = a.clamp_half ? fmaxf(0.5f, minPos) : minPos;
@@ -204,7 +246,7 @@ __global__ __launch_bounds__(256) void ssd_disparity_kernel(const SsdArgs* __res
 
 void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream) {
     if (max_n <= 0) return;
-    hipLaunchKernelGGL(ssd_disparity_kernel, dim3(max_n, batch), dim3(256), 0, stream, d_args);
+    hipLaunchKernelGGL(ssd_disparity_kernel, dim3(max_n, batch), dim3(SSD_THREADS), 0, stream, d_args);
 }
 
 // -------------------------------------------------------------------------

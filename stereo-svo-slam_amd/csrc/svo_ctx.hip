@@ -186,6 +186,10 @@ struct Seq {
     std::vector<svo_pose> trajectory;
     svo_frame_stats stats;
     int n_host = 0;
+    // pose-filter update of the last frame, deferred so that it overlaps the next frame's kernels
+    bool pending = false;
+    float pending_pose[6] = {0, 0, 0, 0, 0, 0};
+    double pending_ts = 0;
 };
 
 }  // namespace
@@ -333,6 +337,33 @@ int new_keyframe_storage(svo_ctx* c, Seq& q, int s, int id) {
 }
 
 }  // namespace
+
+// motion + 12-state filter + trajectory of the last frame (stereo_slam.cpp:250-270).
+// Deferred: the next frame's pose guess only needs the state BEFORE this update
+// (kf.statePre after its predict() equals the current statePost, dt = 0), so the
+// host runs it while the GPU already works on the next frame.
+static void flush_pending(svo_ctx* c) {
+    for (Seq& q : c->seqs) {
+        if (!q.pending) continue;
+        q.pending = false;
+        float prev_pose[6];
+        std::memcpy(prev_pose, q.pose, sizeof(prev_pose));
+        std::memcpy(q.pose, q.pending_pose, sizeof(q.pose));
+        const double dt = q.pending_ts - q.ts;
+        const double inv = 1. / dt;
+        float motion[6];
+        for (int i = 0; i < 6; i++) motion[i] = (float)((q.pose[i] - prev_pose[i]) * inv);
+        const float pv[6] = {0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f};
+        const float mv[6] = {1, 1, 1, 1, 1, 1};
+        float filtered[6];
+        q.kf.update(q.pose, motion, pv, mv, 0.0, filtered);
+        std::memcpy(q.pose, filtered, sizeof(q.pose));
+        q.ts = q.pending_ts;
+        svo_pose p;
+        std::memcpy(&p, q.pose, sizeof(p));
+        q.trajectory.push_back(p);
+    }
+}
 
 extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
                               int device, svo_ctx** out) {
@@ -483,64 +514,59 @@ extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
     return SVO_OK;
 }
 
-// keyframe creation for the sequences whose enable flag is set (device predicate)
+// keyframe creation for the sequences flagged in `need`: their argument blocks are
+// packed into the first m slots, so the five launches cover exactly those sequences
 static int enqueue_keyframes(svo_ctx* c, const std::vector<int>& need, bool first_frame) {
     const int B = c->B;
+    int m = 0;
     for (int s = 0; s < B; s++) {
+        if (!need[s]) continue;
         Seq& q = c->seqs[s];
-        *args_at<int>(c, c->off_enable, s) = need[s];
-        const int* d_en = dargs_at<int>(c, c->off_enable, s);
-        if (!need[s]) {
-            args_at<CompactArgs>(c, c->off_compact, s)->enable = d_en;
-            args_at<DetectArgs>(c, c->off_det, s)->enable = d_en;
-            args_at<MergeArgs>(c, c->off_merge, s)->enable = d_en;
-            args_at<SsdArgs>(c, c->off_ssd, s)->enable = d_en;
-            args_at<KfInitArgs>(c, c->off_init, s)->enable = d_en;
-            continue;
-        }
+        const int slot = m++;
         const int id = (int)q.kfs.size();
         int rc = new_keyframe_storage(c, q, s, id);
         if (rc) return rc;
         // find_bad_keypoints: cur -> other, then the other set is current
-        CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, s);
+        CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, slot);
+        std::memset(ca, 0, sizeof(*ca));
         ca->src = q.kps[q.cur]; ca->dst = q.kps[q.cur ^ 1]; ca->mode = 1;
-        ca->width = c->width; ca->height = c->height; ca->enable = d_en;
+        ca->width = c->width; ca->height = c->height;
         q.cur ^= 1;
-        DetectArgs* da = args_at<DetectArgs>(c, c->off_det, s);
+        DetectArgs* da = args_at<DetectArgs>(c, c->off_det, slot);
         std::memset(da, 0, sizeof(*da));
         for (int l = 0; l < c->cam.max_pyramid_levels; l++) da->level[l] = q.cur_set->left[l];
         da->n_levels = c->det_levels; da->grid_w = c->cam.grid_width; da->grid_h = c->cam.grid_height;
-        da->out = q.det; da->n_out = q.n_det; da->max_cells = c->max_cells; da->enable = d_en;
-        MergeArgs* ma = args_at<MergeArgs>(c, c->off_merge, s);
+        da->out = q.det; da->n_out = q.n_det; da->max_cells = c->max_cells;
+        MergeArgs* ma = args_at<MergeArgs>(c, c->off_merge, slot);
         std::memset(ma, 0, sizeof(*ma));
         ma->cam = c->cam; ma->width = c->width; ma->height = c->height;
         ma->det = q.det; ma->n_det = q.n_det; ma->n_levels = c->det_levels; ma->max_cells = c->max_cells;
         ma->kps = q.kps[q.cur]; ma->cap = c->cap;
         ma->sel = q.sel; ma->sel_level = q.sel_level; ma->sel_cell = q.sel_cell; ma->occupied = q.occupied;
-        ma->old_count = &c->d_res[s].old_count; ma->overflow = &c->d_res[s].overflow; ma->enable = d_en;
-        SsdArgs* sa = args_at<SsdArgs>(c, c->off_ssd, s);
+        ma->old_count = &c->d_res[s].old_count; ma->overflow = &c->d_res[s].overflow;
+        SsdArgs* sa = args_at<SsdArgs>(c, c->off_ssd, slot);
         std::memset(sa, 0, sizeof(*sa));
         sa->left = q.cur_set->left[0]; sa->right = q.cur_set->right;
         sa->n_ptr = q.kps[q.cur].n; sa->kps2d = q.kps[q.cur].kps2d; sa->disparity = q.disparity;
         sa->win = c->cam.window_size_depth_calculator; sa->search_x = c->cam.search_x;
         sa->search_y = c->cam.search_y; sa->clamp_half = 0;
-        sa->first = 0; sa->first_ptr = &c->d_res[s].old_count; sa->enable = d_en;
-        KfInitArgs* ia = args_at<KfInitArgs>(c, c->off_init, s);
+        sa->first = 0; sa->first_ptr = &c->d_res[s].old_count;
+        KfInitArgs* ia = args_at<KfInitArgs>(c, c->off_init, slot);
         std::memset(ia, 0, sizeof(*ia));
         ia->cam = c->cam; ia->kps = q.kps[q.cur]; ia->old_count = &c->d_res[s].old_count;
         ia->disparity = q.disparity; ia->frame_pose = c->d_res[s].pose_refined;
         ia->first_frame = first_frame ? 1 : 0; ia->new_kf_id = id; ia->kfs = q.d_kfs;
-        ia->color_lcg = q.color_lcg; ia->n_out = &c->d_res[s].kf_n; ia->enable = d_en;
+        ia->color_lcg = q.color_lcg; ia->n_out = &c->d_res[s].kf_n;
+        HIP_TRY(hipMemsetAsync(q.n_det, 0, sizeof(int) * SVO_MAX_PYRAMID_LEVELS, c->stream));
     }
+    if (m == 0) return SVO_OK;
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
-    for (int s = 0; s < B; s++)
-        if (need[s]) HIP_TRY(hipMemsetAsync(c->seqs[s].n_det, 0, sizeof(int) * SVO_MAX_PYRAMID_LEVELS, c->stream));
-    launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
+    launch_compact(dargs_at<CompactArgs>(c, c->off_compact), m, c->stream);
     if (c->det_levels > 0)
-        launch_detect(dargs_at<DetectArgs>(c, c->off_det), B, c->max_cells, c->det_levels, c->stream);
-    launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), B, c->stream);
-    launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, c->cap, c->stream);
-    launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), B, c->stream);
+        launch_detect(dargs_at<DetectArgs>(c, c->off_det), m, c->max_cells, c->det_levels, c->stream);
+    launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), m, c->stream);
+    launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), m, c->cap, c->stream);
+    launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), m, c->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -593,7 +619,8 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             FrameResult* dr = c->d_res + s;
             // predicted pose = kf.statePre (stereo_slam.cpp:183-192)
             float* guess = args_at<float>(c, c->off_guess, s * 8);
-            for (int i = 0; i < 6; i++) guess[i] = q.kf.statePre[i];
+            // (== statePost while the previous frame's filter update is still pending, dt = 0)
+            for (int i = 0; i < 6; i++) guess[i] = q.pending ? q.kf.statePost[i] : q.kf.statePre[i];
             const float* d_guess = dargs_at<float>(c, c->off_guess, s * 8);
             // remove_outliers: previous set -> other set (becomes the frame's keypoints)
             CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, s);
@@ -676,6 +703,7 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         SVO_MARK(7);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
+        flush_pending(c);                 // previous frame's pose filter, overlapped with the kernels
         HIP_TRY(hipStreamSynchronize(c->stream));
         // KeyFrameManager::keyframe_needed (keyframe_manager.cpp:66-72)
         const int max_keypoints = (c->width / c->cam.grid_width) * (c->height / c->cam.grid_height);
@@ -703,38 +731,30 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     }
     const float sia_ms = stage_ms[2];
 
-    // ---- host bookkeeping: pose filter, trajectory (stereo_slam.cpp:250-270)
+    // ---- host bookkeeping (stereo_slam.cpp:250-270); the pose filter itself is deferred
     for (int s = 0; s < B; s++) {
         Seq& q = c->seqs[s];
         const FrameResult& r = c->h_res[s];
         const double ts = (double)time_stamps[s];
-        float prev_pose[6];
-        std::memcpy(prev_pose, q.pose, sizeof(prev_pose));
         q.frame_id++;
         if (first) {
             std::memset(q.pose, 0, sizeof(q.pose));
+            q.ts = ts;
+            svo_pose p;
+            std::memcpy(&p, q.pose, sizeof(p));
+            q.trajectory.push_back(p);
         } else {
-            std::memcpy(q.pose, r.pose_refined, sizeof(q.pose));
-            const double dt = ts - q.ts;
-            const double inv = 1. / dt;
-            float motion[6];
-            for (int i = 0; i < 6; i++) motion[i] = (float)((q.pose[i] - prev_pose[i]) * inv);
-            const float pv[6] = {0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f};
-            const float mv[6] = {1, 1, 1, 1, 1, 1};
-            float filtered[6];
-            q.kf.update(q.pose, motion, pv, mv, 0.0, filtered);
-            std::memcpy(q.pose, filtered, sizeof(q.pose));
+            q.pending = true;
+            std::memcpy(q.pending_pose, r.pose_refined, sizeof(q.pending_pose));
+            q.pending_ts = ts;
         }
-        q.ts = ts;
         if (need[s]) {
             KfHost& k = q.kfs.back();
             k.n = r.kf_n;
-            std::memcpy(k.pose, first ? q.pose : r.pose_refined, sizeof(k.pose));
+            if (first) std::memset(k.pose, 0, sizeof(k.pose));
+            else std::memcpy(k.pose, r.pose_refined, sizeof(k.pose));
         }
         q.n_host = c->h_n[2 * s + q.cur];
-        svo_pose p;
-        std::memcpy(&p, q.pose, sizeof(p));
-        q.trajectory.push_back(p);
         svo_frame_stats& st = q.stats;
         std::memset(&st, 0, sizeof(st));
         st.frame_id = q.frame_id; st.is_keyframe = need[s]; st.n_keypoints = q.n_host;
@@ -784,6 +804,7 @@ extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, c
 
 extern "C" int svo_get_pose(svo_ctx* c, int seq, float pose[6]) {
     CHECK_SEQ(c, seq);
+    flush_pending(c);
     std::memcpy(pose, c->seqs[seq].pose, sizeof(float) * 6);
     return SVO_OK;
 }
@@ -854,6 +875,7 @@ extern "C" int svo_get_keyframe(svo_ctx* c, int seq, int id, svo_kp2d* kps2d, sv
 
 extern "C" int svo_get_trajectory(svo_ctx* c, int seq, svo_pose* out, int cap, int* n) {
     CHECK_SEQ(c, seq);
+    flush_pending(c);
     Seq& q = c->seqs[seq];
     if (n) *n = (int)q.trajectory.size();
     const int m = std::min<int>(cap, (int)q.trajectory.size());
@@ -865,6 +887,7 @@ extern "C" int svo_update_pose(svo_ctx* c, int seq, const float pose[6], const f
                                const float pose_var[6], const float speed_var[6], double dt,
                                float filtered[6]) {
     CHECK_SEQ(c, seq);
+    flush_pending(c);
     c->seqs[seq].kf.update(pose, speed, pose_var, speed_var, dt, filtered);
     return SVO_OK;
 }

@@ -126,29 +126,38 @@ class Scene:
                 off=(float(rng.uniform(0, 1024)), float(rng.uniform(0, 1024)))))
 
     def render_batch(self, cfg, poses, right=False):
-        """float32 [K, height, width] noise-free images of the camera at poses [K, 6]."""
+        """float32 [K, height, width] noise-free images of the camera at poses [K, 6].
+        Per-pixel math is float32 and purely elementwise (no BLAS calls)."""
         dev = self.device
         w, h = cfg["width"], cfg["height"]
         poses = np.asarray(poses, np.float64).reshape(-1, 6)
         K = poses.shape[0]
-        R = torch.tensor(np.stack([rodrigues(p[3:6]) for p in poses]), dtype=torch.float64, device=dev)
-        o = torch.tensor(poses[:, 0:3], dtype=torch.float64, device=dev)
+        Rn = np.stack([rodrigues(p[3:6]) for p in poses])                  # [K,3,3] float64
+        on = poses[:, 0:3].copy()
         if right:
             b = cfg["baseline"] / cfg["fx"]
-            o = o + (R @ torch.tensor([-b, 0.0, 0.0], dtype=torch.float64, device=dev))
-        xs = (torch.arange(w, dtype=torch.float64, device=dev) - cfg["cx"]) / cfg["fx"]
-        ys = (torch.arange(h, dtype=torch.float64, device=dev) - cfg["cy"]) / cfg["fy"]
-        dc = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w),
-                          torch.ones(h, w, dtype=torch.float64, device=dev)], -1)
-        d = torch.einsum("hwc,kdc->khwd", dc, R)                  # world ray directions [K,h,w,3]
-        best_s = torch.full((K, h, w), float("inf"), dtype=torch.float64, device=dev)
-        img = torch.zeros(K, h, w, dtype=torch.float32, device=dev)
+            on = on + Rn @ np.array([-b, 0.0, 0.0])
+        f32 = torch.float32
+        R = torch.tensor(Rn, dtype=f32, device=dev)
+        o = torch.tensor(on, dtype=f32, device=dev)
+        xs = ((torch.arange(w, dtype=torch.float64, device=dev) - cfg["cx"]) / cfg["fx"]).to(f32)
+        ys = ((torch.arange(h, dtype=torch.float64, device=dev) - cfg["cy"]) / cfg["fy"]).to(f32)
+        X = xs[None, None, :]
+        Y = ys[None, :, None]
+        # world ray directions d = R (x, y, 1), one [K,h,w] tensor per component
+        d = [R[:, i, 0, None, None] * X + R[:, i, 1, None, None] * Y + R[:, i, 2, None, None]
+             for i in range(3)]
+        best_s = torch.full((K, h, w), float("inf"), dtype=f32, device=dev)
+        img = torch.zeros(K, h, w, dtype=f32, device=dev)
         for pl in self.planes:
-            n = torch.linalg.cross(pl["u"], pl["v"])
-            dn = d @ n
-            s = ((pl["p0"] - o) @ n)[:, None, None] / dn
-            q = o[:, None, None, :] + s[..., None] * d - pl["p0"]
-            tu, tv = q @ pl["u"], q @ pl["v"]
+            u, v, p0 = (pl[k].to(f32) for k in ("u", "v", "p0"))
+            n = torch.linalg.cross(u, v)
+            dn = d[0] * n[0] + d[1] * n[1] + d[2] * n[2]
+            num = ((p0[None, :] - o) * n[None, :]).sum(1)                  # [K]
+            s = num[:, None, None] / dn
+            q = [o[:, i, None, None] + s * d[i] - p0[i] for i in range(3)]
+            tu = q[0] * u[0] + q[1] * u[1] + q[2] * u[2]
+            tv = q[0] * v[0] + q[1] * v[1] + q[2] * v[2]
             del q
             ok = (s > 1e-3) & (s < best_s) & torch.isfinite(s)
             if pl["hu"] > 0:
@@ -157,19 +166,20 @@ class Scene:
             fv = tv * self.tpm + pl["off"][1]
             del tu, tv
             iu, iv = torch.floor(fu), torch.floor(fv)
-            au, av = (fu - iu).float(), (fv - iv).float()
+            au, av = fu - iu, fv - iv
             size = pl["tex"].shape[0]
-            iu0 = torch.remainder(iu, size).long()
-            iv0 = torch.remainder(iv, size).long()
+            iu0 = torch.remainder(iu, size).to(torch.int32)
+            iv0 = torch.remainder(iv, size).to(torch.int32)
             del fu, fv, iu, iv
-            zero = torch.zeros_like(iu0)
-            iu0 = torch.where(ok, iu0, zero)
-            iv0 = torch.where(ok, iv0, zero)
+            iu0 = torch.where(ok, iu0, 0)
+            iv0 = torch.where(ok, iv0, 0)
             iu1 = torch.remainder(iu0 + 1, size)
             iv1 = torch.remainder(iv0 + 1, size)
-            t = pl["tex"]
-            val = (t[iv0, iu0] * (1 - au) * (1 - av) + t[iv0, iu1] * au * (1 - av) +
-                   t[iv1, iu0] * (1 - au) * av + t[iv1, iu1] * au * av)
+            t = pl["tex"].reshape(-1)
+            i00 = (iv0 * size + iu0).long(); i01 = (iv0 * size + iu1).long()
+            i10 = (iv1 * size + iu0).long(); i11 = (iv1 * size + iu1).long()
+            val = (t[i00] * (1 - au) * (1 - av) + t[i01] * au * (1 - av) +
+                   t[i10] * (1 - au) * av + t[i11] * au * av)
             img = torch.where(ok, val, img)
             best_s = torch.where(ok, s, best_s)
         return img
