@@ -103,10 +103,13 @@ struct LevelCtx {
     int patch;              // window_size_pose_estimator
     // per patch pixel (n*16): reference cost sample, gradients, reference patch sum
     float* rec_i1; float* rec_g0; float* rec_g1; float* rec_ps;
-    // per keypoint (cap): point + active flag, sum g g^T
+    // per keypoint: point + active flag, sum g g^T
     v4f* kp_pt; v4f* kp_G;
-    v2f* proj;              // always LDS
-    float* slot;            // [64 groups][28]: J, (sum g g^T) J and the two residual sums of a patch (LDS)
+    v2f* proj;              // projection at the pose of the last evaluation (always LDS)
+    v4f* kp_cw;             // bilinear weights of the cost patch at that projection
+    int* kp_cb;             // byte offset of its first tap in the current level image, < 0: outside
+    float* kp_J;            // [n][12] Jacobian of the last evaluated pose (gradient only)
+    float* kp_rows;         // [n][8]  x and y of the four patch rows as the reference's loops reach them
 };
 
 __device__ inline float block_sum1(float v, SiaShared& sh) {
@@ -120,7 +123,9 @@ __device__ inline float block_sum1(float v, SiaShared& sh) {
     return s;   // same order in every thread
 }
 
-// do_calc: project + get_total_intensity_diff
+// do_calc: project + get_total_intensity_diff. Phase B (one thread per keypoint)
+// projects and derives the bilinear weights / first tap of the 4x4 cost patch;
+// phase C (one thread per patch pixel) is 1 record read, 4 taps and 8 flops.
 template <bool LDS>
 __device__ float sia_cost(const SiaArgs& a, int n, const LevelCtx<LDS>& L, const float pose[6], SiaShared& sh) {
     const int tid = threadIdx.x;
@@ -131,39 +136,47 @@ __device__ float sia_cost(const SiaArgs& a, int n, const LevelCtx<LDS>& L, const
     SIA_STAMP(c2);
     __syncthreads();
     const CamD camd = make_camd(L.fx, L.fy, L.cx, L.cy, a.cam);
+    const int ps = L.patch;
+    const float half_size = ((float)ps - 1.0f) / 2.0f;
     for (int i = tid; i < n; i += SIA_THREADS) {
         const v4f p = mem_ld<LDS>(L.kp_pt, i);
+        int cb = -1;
+        v4f cw = {0, 0, 0, 0};
         if (p.w != 0.f) {
             const svo_kp2d q = project_point(sh.pm.Rd, sh.pm.t, camd, svo_kp3d{p.x, p.y, p.z});
-            mem_st<true>(L.proj, i, v2f{q.x, q.y});
+            mem_st<LDS>(L.proj, i, v2f{q.x, q.y});
+            const float s2x = q.x - half_size, s2y = q.y - half_size;
+            const float f2x = floorf(s2x), f2y = floorf(s2y);
+            // (absurd projections are kept out of the int conversion)
+            if (f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f) {
+                const int ip2x = (int)f2x, ip2y = (int)f2y;
+                if (ip2y + ps < L.cur.h && ip2x + ps < L.cur.w) {
+                    const float x22 = s2x - (float)ip2x, y22 = s2y - (float)ip2y;
+                    const float x21 = 1.0f - x22, y21 = 1.0f - y22;
+                    cw = v4f{x21 * y21, x22 * y21, x21 * y22, x22 * y22};
+                    cb = ip2y * L.cur.stride + ip2x;
+                }
+            }
         }
+        mem_st<LDS>(L.kp_cw, i, cw);
+        mem_st<LDS>(L.kp_cb, i, cb);
     }
     SIA_STAMP(c3);
     __syncthreads();
     SIA_STAMP(c4);
     float v = 0;
-    const int ps = L.patch;
-    const float half_size = ((float)ps - 1.0f) / 2.0f;
     for (int idx = tid; idx < n * 16; idx += SIA_THREADS) {
         const int kp = idx >> 4, px = idx & 15;
         const float i1 = mem_ld<LDS>(L.rec_i1, idx);
-        if (i1 != i1) continue;                      // reference half invalid / inactive
-        const v2f q = mem_ld<true>(L.proj, kp);
-        const float s2x = q.x - half_size, s2y = q.y - half_size;
-        const float f2x = floorf(s2x), f2y = floorf(s2y);
-        // keep absurd projections out of the int conversion
-        if (!(f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f)) continue;
-        const int ip2x = (int)f2x, ip2y = (int)f2y;
-        if (!(ip2y + ps < L.cur.h && ip2x + ps < L.cur.w)) continue;
-        const float x22 = s2x - (float)ip2x, y22 = s2y - (float)ip2y;
-        const float x21 = 1.0f - x22, y21 = 1.0f - y22;
-        const float m0 = x21 * y21, m1 = x22 * y21, m2 = x21 * y22, m3 = x22 * y22;
-        const int yy = (px >> 2) + ip2y, xx = (px & 3) + ip2x;
+        const int cb = mem_ld<LDS>(L.kp_cb, kp);
+        if (i1 != i1 || cb < 0) continue;            // reference or current half outside / inactive
+        const v4f m = mem_ld<LDS>(L.kp_cw, kp);
+        const int o = cb + (px >> 2) * L.cur.stride + (px & 3);
         float i2 = 0;
-        i2 += m0 * (float)L.cur.at(yy, xx);
-        i2 += m1 * (float)L.cur.at(yy, xx + 1);
-        i2 += m2 * (float)L.cur.at(yy + 1, xx);
-        i2 += m3 * (float)L.cur.at(yy + 1, xx + 1);
+        i2 += m.x * (float)mem_ld<LDS>(L.cur.p, o);
+        i2 += m.y * (float)mem_ld<LDS>(L.cur.p, o + 1);
+        i2 += m.z * (float)mem_ld<LDS>(L.cur.p, o + L.cur.stride);
+        i2 += m.w * (float)mem_ld<LDS>(L.cur.p, o + L.cur.stride + 1);
         v += fabsf(i1 - i2);
     }
     SIA_STAMP(c5);
@@ -180,34 +193,63 @@ __constant__ int8_t c_tri_c[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 
 
 // get_gradient (with calculate_hessian) at the pose of the LAST cost evaluation
 // (rotation in sh.pm and projections in L.proj are reused); leaves the step in sh.grad.
-// The 16 lanes of a patch first sum their residual*gradient terms (one DPP row),
-// lane 0 publishes J and (sum g g^T) J of the keypoint in an LDS slot, then every
-// lane owns two of the 27 outputs (21 entries of J^T G J, 6 of -J^T s).
+// Phase B' (one thread per keypoint): Jacobian and the four row starts of the
+// residual patch. Phase C' (one thread per patch pixel): residual * gradient,
+// summed over the 16 lanes of the patch (one DPP row); then every lane owns two
+// of the 27 outputs (21 entries of J^T G J, 6 of -J^T s).
 template <bool LDS>
 __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, SiaShared& sh, float* dbg) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     SIA_STAMP(g0);
+    for (int i = tid; i < n; i += SIA_THREADS) {
+        const v4f pt = mem_ld<LDS>(L.kp_pt, i);
+        float J[12];
+        float rows[8];
+        if (pt.w != 0.f) {
+            float X[3] = {pt.x - sh.pm.t[0], pt.y - sh.pm.t[1], pt.z - sh.pm.t[2]};
+            mat33f_vec(sh.pm.Ri, X, X);
+            pose_jacobian(L.fx, L.fy, X[0], X[1], X[2], J);
+            const v2f q = mem_ld<LDS>(L.proj, i);
+            float x = q.x - 2.f, y = q.y - 2.f;      // x++ per column, x -= 4 and y++ per row
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rows[r] = x; rows[4 + r] = y;
+                x += 1.f; x += 1.f; x += 1.f; x += 1.f;
+                x -= 4.f;
+                y += 1.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++) J[k] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rows[k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) mem_st<LDS>(L.kp_J, i * 12 + k, J[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) mem_st<LDS>(L.kp_rows, i * 8 + k, rows[k]);
+    }
+    __syncthreads();
     float acc_a = 0, acc_b = 0;                      // outputs px and px + 16
     const int px = tid & 15;
     const int oa = px, ob = px + 16;
     const int ra = c_tri_r[oa], ca = c_tri_c[oa];
     const int rb = ob < 21 ? c_tri_r[ob] : ob - 21, cb = ob < 21 ? c_tri_c[ob] : 0;
-    float* slot = L.slot + (tid >> 4) * 28;
     const int npad = (n * 16 + 63) & ~63;            // whole waves take part in the row sums
     for (int idx = tid; idx < npad; idx += SIA_THREADS) {
         const int kp = idx >> 4;
         float s0 = 0, s1 = 0;
-        bool active = false;
-        v4f pt = {0, 0, 0, 0};
-        if (idx < n * 16) {
-            pt = mem_ld<LDS>(L.kp_pt, kp);
-            active = pt.w != 0.f;
+        const bool in = idx < n * 16;
+        if (in) {
             const float psr = mem_ld<LDS>(L.rec_ps, idx);
-            if (active && psr == psr) {              // reference pixel inside (:449-451)
-                const v2f q = mem_ld<true>(L.proj, kp);
-                float kx, ky;
-                patch_pos(q.x - 2.f, q.y - 2.f, px >> 2, px & 3, kx, ky);
+            if (psr == psr) {                        // active and reference pixel inside (:449-451)
+                const int r = px >> 2, c = px & 3;
+                float kx = mem_ld<LDS>(L.kp_rows, kp * 8 + r);
+                const float ky = mem_ld<LDS>(L.kp_rows, kp * 8 + 4 + r);
+                kx += (c > 0) ? 1.f : 0.f;           // x++ per column (adding 0 is exact)
+                kx += (c > 1) ? 1.f : 0.f;
+                kx += (c > 2) ? 1.f : 0.f;
                 if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
                       ((double)kx + 2.0) > L.cur.w || ((double)ky + 2.0) > L.cur.h)) {
                     const float d = patch_sum_img(L.cur, kx, ky) - psr;
@@ -218,41 +260,22 @@ __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, Si
         }
         s0 = row16_sum_dpp(s0);
         s1 = row16_sum_dpp(s1);
-        if (px == 0) {
-            float J[12], M0[6], M1[6];
-            if (active) {
-                float X[3] = {pt.x - sh.pm.t[0], pt.y - sh.pm.t[1], pt.z - sh.pm.t[2]};
-                mat33f_vec(sh.pm.Ri, X, X);
-                pose_jacobian(L.fx, L.fy, X[0], X[1], X[2], J);
-                const v4f G = mem_ld<LDS>(L.kp_G, kp);
-#pragma unroll
-                for (int k = 0; k < 6; k++) {            // (sum g g^T) J
-                    M0[k] = G.x * J[k] + G.y * J[6 + k];
-                    M1[k] = G.y * J[k] + G.z * J[6 + k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 12; k++) J[k] = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) { M0[k] = 0; M1[k] = 0; }
+        if (in) {
+            const float* Jk = L.kp_J + kp * 12;
+            const v4f G = mem_ld<LDS>(L.kp_G, kp);
+            {   // H entry (ra, ca) = J_r^T (G J)_c
+                const float j0c = mem_ld<LDS>(Jk, ca), j1c = mem_ld<LDS>(Jk, 6 + ca);
+                const float m0 = G.x * j0c + G.y * j1c, m1 = G.y * j0c + G.z * j1c;
+                acc_a += mem_ld<LDS>(Jk, ra) * m0 + mem_ld<LDS>(Jk, 6 + ra) * m1;
             }
-#pragma unroll
-            for (int k = 0; k < 12; k++) mem_st<true>(slot, k, J[k]);
-#pragma unroll
-            for (int k = 0; k < 6; k++) { mem_st<true>(slot, 12 + k, M0[k]); mem_st<true>(slot, 18 + k, M1[k]); }
+            if (ob < 21) {
+                const float j0c = mem_ld<LDS>(Jk, cb), j1c = mem_ld<LDS>(Jk, 6 + cb);
+                const float m0 = G.x * j0c + G.y * j1c, m1 = G.y * j0c + G.z * j1c;
+                acc_b += mem_ld<LDS>(Jk, rb) * m0 + mem_ld<LDS>(Jk, 6 + rb) * m1;
+            } else if (ob < 27) {
+                acc_b -= mem_ld<LDS>(Jk, rb) * s0 + mem_ld<LDS>(Jk, 6 + rb) * s1;
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // H entry (ra, ca) and either H entry (rb, cb) or b entry rb
-        acc_a += mem_ld<true>(slot, ra) * mem_ld<true>(slot, 12 + ca) +
-                 mem_ld<true>(slot, 6 + ra) * mem_ld<true>(slot, 18 + ca);
-        if (ob < 21)
-            acc_b += mem_ld<true>(slot, rb) * mem_ld<true>(slot, 12 + cb) +
-                     mem_ld<true>(slot, 6 + rb) * mem_ld<true>(slot, 18 + cb);
-        else if (ob < 27)
-            acc_b -= mem_ld<true>(slot, rb) * s0 + mem_ld<true>(slot, 6 + rb) * s1;
-        __builtin_amdgcn_wave_barrier();                 // slot is rewritten in the next pass
     }
     // the four patches of a wave, then the waves
     acc_a += __shfl_xor(acc_a, 16, 64); acc_a += __shfl_xor(acc_a, 32, 64);
@@ -294,34 +317,34 @@ __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, Si
     __syncthreads();
 }
 
-// LDS carve-up (host and device must agree). "fits": per-keypoint arrays and both
-// copies of the largest level image are in LDS and `rec_floats` floats are left
-// for the records (16 B per patch pixel); otherwise only the projections are.
+// Working set of one sequence, sized by the number of keypoints n:
+//   per keypoint 128 B : projection, cost weights + offset, Jacobian, row starts,
+//                        point + active flag, sum g g^T
+//   per patch pixel 16 B (256 B per keypoint): the per-level records
+//   2 x the largest level image the estimator uses
+// It lives in LDS when it fits the budget (n <= ~250 at 752x480), else in the
+// HBM workspace (SiaArgs::kp_ws / cache). Host and device share this function.
 struct SiaLds {
-    size_t proj, slot, kp_pt, kp_G, img_cur, img_prev, rec, total;
-    int fits, img_bytes, rec_floats;
+    size_t proj, kp_cw, kp_cb, kp_J, kp_rows, kp_pt, kp_G, img_cur, img_prev, rec, total;
+    int img_bytes;
 };
 
-__host__ __device__ inline SiaLds sia_lds_layout(int cap, int max_img_bytes) {
+__host__ __device__ inline SiaLds sia_lds_layout(int n, int max_img_bytes) {
     SiaLds l;
+    const size_t np = ((size_t)n + 15) & ~(size_t)15;
     size_t off = 0;
-    l.proj = off; off += ((size_t)cap * sizeof(svo_kp2d) + 15) & ~(size_t)15;
-    l.slot = off; off += (size_t)(SIA_THREADS / 16) * 28 * 4;
+    l.proj = off;    off += np * 8;
+    l.kp_cb = off;   off += np * 4;
+    l.kp_cw = off;   off += np * 16;
+    l.kp_J = off;    off += np * 48;
+    l.kp_rows = off; off += np * 32;
+    l.kp_pt = off;   off += np * 16;
+    l.kp_G = off;    off += np * 16;
     const size_t img = ((size_t)max_img_bytes + 15) & ~(size_t)15;
-    const size_t want = off + (size_t)cap * 32 + 2 * img;
-    l.fits = (max_img_bytes > 0 && want + 64 * 256 <= SIA_LDS_BUDGET) ? 1 : 0;   // room for >= 64 patches
-    l.kp_pt = l.kp_G = l.img_cur = l.img_prev = l.rec = off;
-    l.img_bytes = 0; l.rec_floats = 0;
-    if (l.fits) {
-        l.kp_pt = off; off += (size_t)cap * 16;
-        l.kp_G = off; off += (size_t)cap * 16;
-        l.img_bytes = (int)img;
-        l.img_cur = off; off += img;
-        l.img_prev = off; off += img;
-        l.rec = off;
-        l.rec_floats = (int)((SIA_LDS_BUDGET - off) / 4);
-        off = SIA_LDS_BUDGET;
-    }
+    l.img_bytes = (int)img;
+    l.img_cur = off; off += img;
+    l.img_prev = off; off += img;
+    l.rec = off;     off += np * 256;
     l.total = off;
     return l;
 }
@@ -330,18 +353,19 @@ template <bool LDS>
 __device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, const SiaLds& lay) {
     const int tid = threadIdx.x;
     LevelCtx<LDS> L;
-    L.proj = reinterpret_cast<v2f*>(dyn + lay.proj);
-    L.slot = reinterpret_cast<float*>(dyn + lay.slot);
-    if (LDS) {
-        L.kp_pt = reinterpret_cast<v4f*>(dyn + lay.kp_pt);
-        L.kp_G = reinterpret_cast<v4f*>(dyn + lay.kp_G);
-        float* r = reinterpret_cast<float*>(dyn + lay.rec);
-        L.rec_i1 = r; L.rec_g0 = r + n * 16; L.rec_g1 = r + 2 * n * 16; L.rec_ps = r + 3 * n * 16;
-    } else {
-        L.kp_pt = reinterpret_cast<v4f*>(a.kp_ws);
-        L.kp_G = reinterpret_cast<v4f*>(a.kp_ws) + a.cap;
-        float* r = reinterpret_cast<float*>(a.cache);
-        const size_t c16 = (size_t)a.cap * 16;
+    {
+        // LDS: the dynamic segment; HBM: kp_ws (cap * 40 floats) and cache (cap * 16 float4)
+        uint8_t* base = LDS ? dyn : reinterpret_cast<uint8_t*>(a.kp_ws);
+        const SiaLds g = LDS ? lay : sia_lds_layout(a.cap, 0);
+        L.proj = reinterpret_cast<v2f*>(base + g.proj);
+        L.kp_cw = reinterpret_cast<v4f*>(base + g.kp_cw);
+        L.kp_cb = reinterpret_cast<int*>(base + g.kp_cb);
+        L.kp_J = reinterpret_cast<float*>(base + g.kp_J);
+        L.kp_rows = reinterpret_cast<float*>(base + g.kp_rows);
+        L.kp_pt = reinterpret_cast<v4f*>(base + g.kp_pt);
+        L.kp_G = reinterpret_cast<v4f*>(base + g.kp_G);
+        float* r = LDS ? reinterpret_cast<float*>(dyn + lay.rec) : reinterpret_cast<float*>(a.cache);
+        const size_t c16 = LDS ? (size_t)(((size_t)n + 15) & ~(size_t)15) * 16 : (size_t)a.cap * 16;
         L.rec_i1 = r; L.rec_g0 = r + c16; L.rec_g1 = r + 2 * c16; L.rec_ps = r + 3 * c16;
     }
     L.patch = a.cam.window_size_pose_estimator;
@@ -506,13 +530,13 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
     const int n = min(*a.n_ptr, a.cap);
     __shared__ SiaShared sh;
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    const SiaLds lay = sia_lds_layout(a.cap, max_img_bytes);
+    const SiaLds lay = sia_lds_layout(n, max_img_bytes);
 #ifdef SVO_SIA_STAMPS
     if (threadIdx.x == 0) for (int i = 0; i < 12; i++) sh.stamp[i] = 0;
     const long long k0 = __builtin_readcyclecounter();
 #endif
-    // everything in LDS when this frame's patches fit, else the HBM workspace
-    if (lay.fits && (size_t)n * 64 <= (size_t)lay.rec_floats) sia_run<true>(a, n, sh, dyn, lay);
+    // the whole working set in LDS when this frame's keypoints fit, else the HBM workspace
+    if (max_img_bytes > 0 && lay.total <= SIA_LDS_BUDGET) sia_run<true>(a, n, sh, dyn, lay);
     else sia_run<false>(a, n, sh, dyn, lay);
 #ifdef SVO_SIA_STAMPS
     if (threadIdx.x == 0 && a.dbg_H) {   // diagnostic build: the debug buffer carries cycle counts
@@ -522,27 +546,29 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
 #endif
 }
 
-static int sia_max_img_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
-    // the largest level (of those the estimator uses) whose two copies still fit
+// largest level image the estimator uses, if two copies of it plus a minimal
+// working set (64 keypoints) fit the LDS budget; 0: run from HBM
+static int sia_max_img_bytes(const svo_camera_settings& cam, int width, int height) {
     int best = 0;
     for (int lv = cam.max_pyramid_levels; lv > cam.min_pyramid_level_pose_estimation; lv--) {
         const int level = lv - 1;
         const int b = (width >> level) * (height >> level);
-        const SiaLds l = sia_lds_layout(cap, b);
-        if (l.fits && b > best) best = b;
+        if (b > best) best = b;
     }
-    return best;
+    return sia_lds_layout(64, best).total <= SIA_LDS_BUDGET ? best : 0;
 }
 
 size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
-    return sia_lds_layout(cap, sia_max_img_bytes(cam, width, height, cap)).total;
+    (void)cap;
+    return sia_max_img_bytes(cam, width, height) > 0 ? SIA_LDS_BUDGET : 0;
 }
 
 void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int cap, hipStream_t stream) {
+    (void)cap;
     static size_t configured = 0;
-    const int img = sia_max_img_bytes(cam, width, height, cap);
-    const size_t lds_bytes = sia_lds_layout(cap, img).total;
+    const int img = sia_max_img_bytes(cam, width, height);
+    const size_t lds_bytes = img > 0 ? SIA_LDS_BUDGET : 0;
     if (lds_bytes > configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

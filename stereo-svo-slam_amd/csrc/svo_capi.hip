@@ -74,7 +74,7 @@ extern "C" int svo_handle_create(int device, int max_keypoints, svo_handle** out
     h->ring_off = 0;
     HIP_TRY(hipMalloc(&h->ring, h->ring_cap));
     HIP_TRY(hipMalloc(&h->sia_cache, sizeof(float4) * 16 * (size_t)max_keypoints));
-    HIP_TRY(hipMalloc(&h->sia_kpws, sizeof(float) * 8 * (size_t)max_keypoints));
+    HIP_TRY(hipMalloc(&h->sia_kpws, sizeof(float) * 40 * (size_t)(max_keypoints + 16)));
     HIP_TRY(hipMalloc(&h->kf_one, sizeof(KfDev)));
     *out = h;
     return SVO_OK;

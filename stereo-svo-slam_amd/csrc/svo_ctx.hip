@@ -453,7 +453,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
         if ((rc = dev_alloc(c, &q.klt_status, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.disparity, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.sia_cache, (size_t)c->cap * 16))) return rc;
-        if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)c->cap * 8))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)(c->cap + 16) * 40))) return rc;
         if ((rc = dev_alloc(c, &q.d_kfs, (size_t)c->max_kf))) return rc;
         if ((rc = dev_alloc(c, &q.det, (size_t)SVO_MAX_PYRAMID_LEVELS * c->max_cells))) return rc;
         if ((rc = dev_alloc(c, &q.n_det, (size_t)SVO_MAX_PYRAMID_LEVELS))) return rc;

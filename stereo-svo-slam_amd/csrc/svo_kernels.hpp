@@ -38,7 +38,7 @@ struct SiaArgs {
     float* cost_out;              // [1]
     svo_gn_trace* trace;          // [SVO_MAX_PYRAMID_LEVELS] or null
     float4* cache;                // workspace [cap*16]: per (kp,px) {gx, gy, ps_prev, i1_prev}
-    float* kp_ws;                 // workspace [cap*8]: per kp {Gxx, Gxy, Gyy, krefx, krefy, active, -, -}
+    float* kp_ws;                 // workspace [(cap+16)*40] floats: per-keypoint arrays when they do not fit LDS
     float* dbg_H;                 // optional [36+6+6]: H, b, step of the first get_gradient of `dbg_level`
     int dbg_level;
     int cap;
