@@ -4,8 +4,8 @@
 // tracking every keypoint from the Gaussian pyramid of its ORIGIN KEYFRAME
 // into the current frame (PoseRefiner::refine_pose, src/lib/pose_refinement.cpp:72-118).
 //
-// One wavefront per keypoint, all pyramid levels and iterations inside the
-// kernel. Per level the (w+3)^2 neighbourhood of the reference point is staged
+// One 128-thread workgroup (two wavefronts) per keypoint, all pyramid levels and
+// iterations inside the kernel. Per level the (w+3)^2 neighbourhood of the reference point is staged
 // in LDS with BORDER_REFLECT_101 addressing, the Scharr derivatives of
 // OpenCV's pyramid are computed from that tile (zero outside the image, as
 // the constant border of cv::buildOpticalFlowPyramid), and the fixed-point
@@ -24,31 +24,57 @@ constexpr int KLT_RW = KLT_MAX_WIN + 3;      // reference tile edge (window + 1 
 constexpr int KLT_DW = KLT_MAX_WIN + 1;      // derivative / tap grid edge
 constexpr int KLT_MARGIN = 6;
 constexpr int KLT_TJ = KLT_DW + 2 * KLT_MARGIN;   // search tile edge
+constexpr int KLT_THREADS = 128;
+constexpr int KLT_WAVES = KLT_THREADS / 64;
+
+// exact 64-bit sum of per-thread int32 partials over the workgroup
+// (DPP row adds per wave, waves combined through LDS), same value in every thread
+template <int NV>
+__device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], long long (*s_part)[4]) {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const long long w = wave_sum_i32_to_i64(v[k]);
+        if ((threadIdx.x & 63) == 0) s_part[wave][k] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        long long t = 0;
+#pragma unroll
+        for (int w = 0; w < KLT_WAVES; w++) t += s_part[w][k];
+        out[k] = t;
+    }
+    __syncthreads();
+}
 
 #define SVO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 __device__ inline int cv_round(float v) { return (int)rintf(v); }
 __device__ inline int cv_floor(float v) { return (int)floorf(v); }
 
-__global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict__ args) {
+__global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* __restrict__ args) {
     const KltArgs& a = args[blockIdx.y];
     const int n = *a.n_ptr;
     const int kp = blockIdx.x;
     if (kp >= n) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;          // thread index in the workgroup
     const int win = a.win;
     const int RW = win + 3, DW = win + 1, TJ = DW + 2 * KLT_MARGIN;
-    // lane -> (row offset, column): two rows per step when a row fits in half a wave
+    // thread -> (row offset, column): a row takes half a wave when it fits, else a whole wave
     const bool two = DW <= 32;
-    const int lc = two ? (lane & 31) : lane;
-    const int lr = two ? (lane >> 5) : 0;
-    const int rstep = two ? 2 : 1;
+    const int lc = two ? (lane & 31) : (lane & 63);
+    const int lr = two ? (lane >> 5) : (lane >> 6);
+    const int rstep = two ? KLT_THREADS / 32 : KLT_THREADS / 64;
+    // tile loads: one thread per column, the rows split over the threads sharing that column
+    const int tcol = lane & 63, trow0 = lane >> 6;
 
     __shared__ uint8_t s_I[KLT_RW * KLT_RW];
     __shared__ int s_d[KLT_DW * KLT_DW];          // packed (dx, dy) int16
     __shared__ short s_Iw[KLT_MAX_WIN * KLT_MAX_WIN];
     __shared__ int s_dIw[KLT_MAX_WIN * KLT_MAX_WIN];
     __shared__ uint8_t s_J[KLT_TJ * KLT_TJ];
+    __shared__ long long s_part[KLT_WAVES][4];
 
     const int kfid = a.kf_id ? a.kf_id[kp] : 0;
     const KfDev& kf = a.kfs[kfid];
@@ -107,9 +133,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
 
         __syncthreads();
         // (w+3)^2 tile of I around the window, rows iprevy-1 .., reflect-101
-        if (lane < RW) {
-            const int gx = reflect101(iprevx - 1 + lane, I.w);
-            for (int r0 = 0; r0 < RW; r0 += 8) {       // 8 independent loads in flight
+        if (tcol < RW) {
+            const int gx = reflect101(iprevx - 1 + tcol, I.w);
+            for (int r0 = trow0 * 8; r0 < RW; r0 += 8 * KLT_WAVES) {   // 8 independent loads in flight
                 uint8_t v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -118,7 +144,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    if (r0 + u < RW) s_I[(r0 + u) * KLT_RW + lane] = v[u];
+                    if (r0 + u < RW) s_I[(r0 + u) * KLT_RW + tcol] = v[u];
             }
         }
         __syncthreads();
@@ -161,8 +187,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                 a11 += ixval * ixval; a12 += ixval * iyval; a22 += iyval * iyval;
             }
         }
-        const long long iA11 = wave_sum_i32_to_i64(a11), iA12 = wave_sum_i32_to_i64(a12),
-                        iA22 = wave_sum_i32_to_i64(a22);
+        long long sA[3];
+        {
+            const int pa[3] = {a11, a12, a22};
+            klt_block_sum<3>(pa, sA, s_part);
+        }
+        const long long iA11 = sA[0], iA12 = sA[1], iA22 = sA[2];
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE,
                     A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -182,9 +212,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
         auto load_tile = [&](int cx, int cy) {
             tx0 = cx - KLT_MARGIN; ty0 = cy - KLT_MARGIN;
             __syncthreads();
-            if (lane < TJ) {
-                const int gx = reflect101(tx0 + lane, J.w);
-                for (int r0 = 0; r0 < TJ; r0 += 8) {
+            if (tcol < TJ) {
+                const int gx = reflect101(tx0 + tcol, J.w);
+                for (int r0 = trow0 * 8; r0 < TJ; r0 += 8 * KLT_WAVES) {
                     uint8_t v[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
@@ -193,7 +223,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (r0 + u < TJ) s_J[(r0 + u) * KLT_TJ + lane] = v[u];
+                        if (r0 + u < TJ) s_J[(r0 + u) * KLT_TJ + tcol] = v[u];
                 }
             }
             __syncthreads();
@@ -226,7 +256,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                     b2 += diff * (dI >> 16);
                 }
             }
-            const long long ib1 = wave_sum_i32_to_i64(b1), ib2 = wave_sum_i32_to_i64(b2);
+            long long sB[2];
+            {
+                const int pb[2] = {b1, b2};
+                klt_block_sum<2>(pb, sB, s_part);
+            }
+            const long long ib1 = sB[0], ib2 = sB[1];
             const float fb1 = (float)ib1 * FLT_SCALE, fb2 = (float)ib2 * FLT_SCALE;
             const float dx = (float)((A12 * fb2 - A22 * fb1) * D);
             const float dy = (float)((A12 * fb1 - A11 * fb2) * D);
@@ -265,8 +300,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
                     e += diff < 0 ? -diff : diff;
                 }
             }
-            e = wave_sum_dpp_i(e);   // < 2^24: the float sum of |diff| is exact in any order
-            const float errval = (float)e;
+            long long sE[1];
+            {
+                const int pe[1] = {e};
+                klt_block_sum<1>(pe, sE, s_part);   // < 2^24: the float sum of |diff| is exact in any order
+            }
+            const float errval = (float)(int)sE[0];
             err = errval * 1.f / (32 * win * win);
         }
     }
@@ -281,7 +320,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(const KltArgs* __restrict
 void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream) {
     (void)win;
     if (max_n <= 0) return;
-    hipLaunchKernelGGL(klt_track_kernel, dim3(max_n, batch), dim3(64), 0, stream, d_args);
+    hipLaunchKernelGGL(klt_track_kernel, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
 }
 
 }  // namespace svo
