@@ -462,6 +462,8 @@ void svo_oi_lkpyr_free(svo_oi_lkpyr *p)
 
 /* diagnostics: LK iterations executed since the last reset (not part of any result) */
 static long long g_lk_iterations = 0, g_lk_points = 0;
+static int g_lk_hist[4096]; static int g_lk_cur = 0;
+int svo_o_lk_hist(int *out, int cap) { int n = g_lk_cur < cap ? g_lk_cur : cap; for (int i = 0; i < n; i++) out[i] = g_lk_hist[i]; g_lk_cur = 0; memset(g_lk_hist, 0, sizeof(g_lk_hist)); return n; }
 long long svo_o_lk_iterations(int reset)
 {
     long long v = g_lk_iterations;
@@ -559,6 +561,7 @@ void svo_oi_klt_track(const svo_oi_lkpyr *P, const svo_oi_lkpyr *N, const svo_kp
 
             for (int j = 0; j < maxCount; j++) {
                 g_lk_iterations++;
+                if (ptidx < 4096) { g_lk_hist[ptidx]++; if (ptidx + 1 > g_lk_cur) g_lk_cur = ptidx + 1; }
                 const int inextx = cv_floor_f(nextx), inexty = cv_floor_f(nexty);
                 if (inextx < -win || inextx >= Jcols || inexty < -win || inexty >= Jrows) {
                     if (level == 0) status[ptidx] = 0;

@@ -24,7 +24,10 @@ constexpr int KLT_RW = KLT_MAX_WIN + 3;      // reference tile edge (window + 1 
 constexpr int KLT_DW = KLT_MAX_WIN + 1;      // derivative / tap grid edge
 constexpr int KLT_MARGIN = 6;
 constexpr int KLT_TJ = KLT_DW + 2 * KLT_MARGIN;   // search tile edge
-constexpr int KLT_THREADS = 128;
+#ifndef SVO_KLT_THREADS
+#define SVO_KLT_THREADS 128
+#endif
+constexpr int KLT_THREADS = SVO_KLT_THREADS;
 constexpr int KLT_WAVES = KLT_THREADS / 64;
 
 // exact 64-bit sum of per-thread int32 partials over the workgroup
@@ -49,6 +52,10 @@ __device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], l
 }
 
 #define SVO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+// every product in the window loops has operands below 2^23 in magnitude (pixels < 2^8,
+// weights <= 2^14, derivatives < 2^13, differences < 2^14): full-rate 24-bit multiplies
+// instead of the quarter-rate 32-bit v_mul_lo_u32
+#define M24(a, b) __mul24((a), (b))
 
 __device__ inline int cv_round(float v) { return (int)rintf(v); }
 __device__ inline int cv_floor(float v) { return (int)floorf(v); }
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int gy = reflect101(iprevy - 1 + min(r0 + u, RW - 1), I.h);
-                    v[u] = I.data[(size_t)gy * I.stride + gx];
+                    v[u] = I.data[M24(gy, I.stride) + gx];   // images are < 2^24 x 2^24, offsets < 2^31
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
@@ -159,10 +166,10 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                     const uint8_t* p0 = &s_I[r * KLT_RW + lc];      // row gy-1, col gx-1
                     const uint8_t* p1 = p0 + KLT_RW;
                     const uint8_t* p2 = p1 + KLT_RW;
-                    const int t0m = (p0[0] + p2[0]) * 3 + p1[0] * 10, t0p = (p0[2] + p2[2]) * 3 + p1[2] * 10;
+                    const int t0m = M24(p0[0] + p2[0], 3) + M24(p1[0], 10), t0p = M24(p0[2] + p2[2], 3) + M24(p1[2], 10);
                     const int t1m = p2[0] - p0[0], t1c = p2[1] - p0[1], t1p = p2[2] - p0[2];
                     const int dx = t0p - t0m;
-                    const int dy = (t1p + t1m) * 3 + t1c * 10;
+                    const int dy = M24(t1p + t1m, 3) + M24(t1c, 10);
                     packed = (dx & 0xffff) | (dy << 16);
                 }
                 s_d[r * KLT_DW + lc] = packed;
@@ -175,16 +182,16 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             for (int y = lr; y < win; y += rstep) {
                 const uint8_t* src = &s_I[(y + 1) * KLT_RW + lc + 1];
                 const int* ds = &s_d[y * KLT_DW + lc];
-                const int ival = SVO_DESCALE(src[0] * iw00 + src[1] * iw01 + src[KLT_RW] * iw10 +
-                                             src[KLT_RW + 1] * iw11, W_BITS - 5);
+                const int ival = SVO_DESCALE(M24(src[0], iw00) + M24(src[1], iw01) + M24(src[KLT_RW], iw10) +
+                                             M24(src[KLT_RW + 1], iw11), W_BITS - 5);
                 const int d00 = ds[0], d01 = ds[1], d10 = ds[KLT_DW], d11 = ds[KLT_DW + 1];
-                const int ixval = SVO_DESCALE((int)(short)d00 * iw00 + (int)(short)d01 * iw01 +
-                                              (int)(short)d10 * iw10 + (int)(short)d11 * iw11, W_BITS);
-                const int iyval = SVO_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 +
-                                              (d10 >> 16) * iw10 + (d11 >> 16) * iw11, W_BITS);
+                const int ixval = SVO_DESCALE(M24((int)(short)d00, iw00) + M24((int)(short)d01, iw01) +
+                                              M24((int)(short)d10, iw10) + M24((int)(short)d11, iw11), W_BITS);
+                const int iyval = SVO_DESCALE(M24(d00 >> 16, iw00) + M24(d01 >> 16, iw01) +
+                                              M24(d10 >> 16, iw10) + M24(d11 >> 16, iw11), W_BITS);
                 s_Iw[y * KLT_MAX_WIN + lc] = (short)ival;
                 s_dIw[y * KLT_MAX_WIN + lc] = (ixval & 0xffff) | (iyval << 16);
-                a11 += ixval * ixval; a12 += ixval * iyval; a22 += iyval * iyval;
+                a11 += M24(ixval, ixval); a12 += M24(ixval, iyval); a22 += M24(iyval, iyval);
             }
         }
         long long sA[3];
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int gy = reflect101(ty0 + min(r0 + u, TJ - 1), J.h);
-                        v[u] = J.data[(size_t)gy * J.stride + gx];
+                        v[u] = J.data[M24(gy, J.stride) + gx];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++)
@@ -248,12 +255,12 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 const uint8_t* jbase = &s_J[(inexty - ty0) * KLT_TJ + (inextx - tx0) + lc];
                 for (int y = lr; y < win; y += rstep) {
                     const uint8_t* jp = jbase + y * KLT_TJ;
-                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_TJ] * iw10 +
-                                                 jp[KLT_TJ + 1] * iw11, W_BITS - 5) -
+                    const int diff = SVO_DESCALE(M24(jp[0], iw00) + M24(jp[1], iw01) + M24(jp[KLT_TJ], iw10) +
+                                                 M24(jp[KLT_TJ + 1], iw11), W_BITS - 5) -
                                      (int)s_Iw[y * KLT_MAX_WIN + lc];
                     const int dI = s_dIw[y * KLT_MAX_WIN + lc];
-                    b1 += diff * (int)(short)dI;
-                    b2 += diff * (dI >> 16);
+                    b1 += M24(diff, (int)(short)dI);
+                    b2 += M24(diff, dI >> 16);
                 }
             }
             long long sB[2];
@@ -294,8 +301,8 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 const uint8_t* jbase = &s_J[(iny - ty0) * KLT_TJ + (inx - tx0) + lc];
                 for (int y = lr; y < win; y += rstep) {
                     const uint8_t* jp = jbase + y * KLT_TJ;
-                    const int diff = SVO_DESCALE(jp[0] * iw00 + jp[1] * iw01 + jp[KLT_TJ] * iw10 +
-                                                 jp[KLT_TJ + 1] * iw11, W_BITS - 5) -
+                    const int diff = SVO_DESCALE(M24(jp[0], iw00) + M24(jp[1], iw01) + M24(jp[KLT_TJ], iw10) +
+                                                 M24(jp[KLT_TJ + 1], iw11), W_BITS - 5) -
                                      (int)s_Iw[y * KLT_MAX_WIN + lc];
                     e += diff < 0 ? -diff : diff;
                 }

@@ -693,11 +693,15 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         SVO_MARK(2);
         launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, c->cap, c->stream);
         SVO_MARK(3);
-        launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, c->cap, c->cam.window_size_opt_flow, c->stream);
+        // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the grid
+        int grid_n = 1;
+        for (int s = 0; s < B; s++) grid_n = std::max(grid_n, c->seqs[s].n_host);
+        grid_n = std::min(grid_n, c->cap);
+        launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, grid_n, c->cam.window_size_opt_flow, c->stream);
         SVO_MARK(4);
         launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), B, c->stream);
         SVO_MARK(5);
-        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, c->cap, c->stream);
+        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, grid_n, c->stream);
         SVO_MARK(6);
         launch_filter(dargs_at<FilterArgs>(c, c->off_filt), B, c->stream);
         SVO_MARK(7);

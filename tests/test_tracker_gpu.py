@@ -96,7 +96,8 @@ def test_first_frame_real_image():
     assert np.array_equal(f.kps3d, k3)
 
 
-@pytest.mark.parametrize("config,n_frames,seed", [("tiny", 12, 0), ("tiny", 12, 3), ("euroc", 8, 0)])
+@pytest.mark.parametrize("config,n_frames,seed", [("tiny", 12, 0), ("tiny", 12, 3), ("euroc", 8, 0),
+                                                  ("econ", 5, 1), ("hd", 3, 0)])
 @pytest.mark.parametrize("exact", [False, True])
 def test_sequence_matches_oracle(config, n_frames, seed, exact):
     _run(config, n_frames, seed, exact=exact)
