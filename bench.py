@@ -115,17 +115,21 @@ def main():
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
     ap.add_argument("--seqs", type=int, default=64, help="sequences per GPU (share every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (default nccl = RCCL). gloo + "
+                         "--share-gpu rehearses the multi-rank path on a single-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
     ap.add_argument("--single", action="store_true",
                     help="also time one sequence alone (latency leg; off by default so that a "
                          "rocprofv3 --stats run of the default command sees only the batched launches)")
     args = ap.parse_args()
 
-    rank, local_rank, world = multi_seq.init_distributed()
+    rank, local_rank, world = multi_seq.init_distributed(args.backend)
     if world != max(args.gpus, 1) and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if (world > 1 and not args.share_gpu) else 0)
     torch.cuda.set_device(device)
 
     B, K, Wm = args.seqs, args.steps, max(args.warmup, 1)
@@ -147,7 +151,8 @@ def main():
             marks["t0"] = slam.totals()
         slam.new_images_packed(packed[k])
 
-    seconds = multi_seq.timed_steps(step_fn, K, Wm, world, device)
+    coll_dev = device if (args.backend or "nccl") == "nccl" else None   # gloo: host tensors
+    seconds = multi_seq.timed_steps(step_fn, K, Wm, world, device, coll_dev)
     t0, t1 = marks["t0"], slam.totals()
     total_frames = B * K * world
     fps = multi_seq.throughput(total_frames, seconds)
@@ -158,7 +163,7 @@ def main():
 
     # one small exchange at the end: per-sequence summaries (id, frames, final pose)
     local = [[sid, K + Wm] + [float(v) for v in slam.pose(i)] for i, sid in enumerate(seq_ids)]
-    summaries = multi_seq.gather_summaries(local, world, device)
+    summaries = multi_seq.gather_summaries(local, world, coll_dev)
 
     if rank != 0:
         return

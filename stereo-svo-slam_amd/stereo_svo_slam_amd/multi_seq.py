@@ -33,6 +33,7 @@ def init_distributed(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
@@ -56,22 +57,26 @@ def _barrier(world, device):
             dist.barrier()
 
 
-def timed_steps(step_fn, steps, warmup, world, device=None):
+def timed_steps(step_fn, steps, warmup, world, device=None, coll_device="same"):
     """Driver contract: `warmup` untimed steps, then exactly `steps` steps bracketed
-    by barrier + device synchronize on both sides; returns MAX-over-ranks seconds."""
+    by barrier + device synchronize on both sides; returns MAX-over-ranks seconds.
+    `device` is synchronized; collectives run on `coll_device` (default: the same;
+    None = host tensors, e.g. gloo)."""
+    if coll_device == "same":
+        coll_device = device
     for k in range(warmup):
         step_fn(k)
     _sync(device)
-    _barrier(world, device)
+    _barrier(world, coll_device)
     _sync(device)
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
         step_fn(k)
     _sync(device)
     t1 = time.perf_counter()
-    _barrier(world, device)
+    _barrier(world, coll_device)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64,
-                           device=device if (device is not None and device.type == "cuda") else "cpu")
+                           device=coll_device if (coll_device is not None and coll_device.type == "cuda") else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     return float(elapsed.item())
