@@ -33,6 +33,9 @@ from stereo_svo_slam_amd import multi_seq, synth
 from stereo_svo_slam_amd.stereo_slam import StereoSlamBatch
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_OF_STAGE = {"sparse_align": "sia_gn_kernel", "klt": "klt_track_kernel",
+                   "reproj_gn": "reproj_gn_kernel", "ssd_disparity": "ssd_disparity_kernel",
+                   "filter_update": "filter_update_kernel", "images+pyramids": "pyr_halfsample_kernel"}
 STAGES = ("images+pyramids", "compaction", "sparse_align", "klt", "reproj_gn", "ssd_disparity",
           "filter_update", "keyframe+readback")
 
@@ -113,7 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--seqs", type=int, default=64, help="sequences per GPU (share every launch)")
+    ap.add_argument("--seqs", type=int, default=256,
+                    help="sequences per GPU (share every launch; 256 = one alignment workgroup per CU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (default nccl = RCCL). gloo + "
@@ -175,8 +179,17 @@ def main():
                      "images+pyramids")
     dom = max(kernel_stages, key=lambda s: named[s])
     achieved = ab[dom] * B / (named[dom] * 1e-3) / 1e9 if named[dom] > 0 else 0.0
+    # HBM bytes per launch from rocprofv3 PMC passes of this command (tools/pmc_traffic.sh ->
+    # profiles/r01_traffic.json); null when that file does not cover this configuration
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj.get("seqs") == B and tj.get("config") == args.config:
+            traffic = tj["bytes_per_launch"].get(KERNEL_OF_STAGE[dom])
+    except Exception:
+        pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": named[dom],
                 "stage_ms_per_step": named,
                 "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
