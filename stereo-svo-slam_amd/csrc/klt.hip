@@ -4,31 +4,88 @@
 // tracking every keypoint from the Gaussian pyramid of its ORIGIN KEYFRAME
 // into the current frame (PoseRefiner::refine_pose, src/lib/pose_refinement.cpp:72-118).
 //
-// One 128-thread workgroup (two wavefronts) per keypoint, all pyramid levels and
-// iterations inside the kernel. Per level the (w+3)^2 neighbourhood of the reference point is staged
-// in LDS with BORDER_REFLECT_101 addressing, the Scharr derivatives of
-// OpenCV's pyramid are computed from that tile (zero outside the image, as
-// the constant border of cv::buildOpticalFlowPyramid), and the fixed-point
-// template (14-bit weights, 5 fractional bits) stays in LDS. The search image
-// is staged once per level as a tile with a 6 px margin around the start
-// position, so an iteration touches HBM only when the window drifts out of
-// it. Lanes map to (row parity, column) of the window, so there is no
-// integer division in the loops; all window sums are exact integers reduced
-// with DPP row adds, so the result does not depend on the reduction order.
+// One workgroup per keypoint, all pyramid levels and iterations inside the
+// kernel. A thread owns one window column and RPT consecutive rows, so
+//  * the bilinear taps slide down the rows: one unaligned 16-bit LDS read per
+//    row, and every 4-tap interpolation is two v_dot2_i32_i16 (14-bit weights
+//    and pixels / derivatives all fit int16);
+//  * the fixed-point template (I, Ix, Iy; 5 fractional bits) of the thread's
+//    rows lives in REGISTERS as int16 row pairs for all iterations of a level:
+//    the mismatch vector is v_pk_sub_i16 + v_dot2 per row pair.
+// Per level the (w+3)^2 neighbourhood of the reference point and a search
+// tile with a 6 px margin are staged in LDS — dword loads when the tile lies
+// inside the image, BORDER_REFLECT_101 byte addressing otherwise — and the
+// Scharr derivatives of OpenCV's pyramid are computed from the LDS tile (zero
+// outside the image, the constant border of cv::buildOpticalFlowPyramid).
+// An iteration touches HBM only when the window drifts out of the search
+// tile. All window sums are exact integers, so the result does not depend on
+// the reduction order.
 #include "svo_kernels.hpp"
+#include <utility>
 
 namespace svo {
 
 constexpr int KLT_MAX_WIN = 35;
-constexpr int KLT_RW = KLT_MAX_WIN + 3;      // reference tile edge (window + 1 tap + 2 Scharr)
-constexpr int KLT_DW = KLT_MAX_WIN + 1;      // derivative / tap grid edge
 constexpr int KLT_MARGIN = 6;
-constexpr int KLT_TJ = KLT_DW + 2 * KLT_MARGIN;   // search tile edge
+constexpr int KLT_DW = KLT_MAX_WIN + 1;                 // derivative / tap grid edge
+constexpr int KLT_RS = 44;                              // row stride of the reference tile: (w+3) + 3 alignment slack, /4
+constexpr int KLT_RROWS = KLT_MAX_WIN + 3;              // also >= 1 + rows covered by the row groups + 1
+constexpr int KLT_TJS = 52;                             // row stride of the search tile: (w+1) + 2*margin + 3, /4
+constexpr int KLT_TJROWS = KLT_DW + 2 * KLT_MARGIN + 2;  // + slack: idle rows of the last row group are read, not used
 #ifndef SVO_KLT_THREADS
 #define SVO_KLT_THREADS 128
 #endif
 constexpr int KLT_THREADS = SVO_KLT_THREADS;
 constexpr int KLT_WAVES = KLT_THREADS / 64;
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ inline v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v); }
+__device__ inline int as_int(v2s v) { return __builtin_bit_cast(int, v); }
+__device__ inline int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+// a.x*b.x + a.y*b.y + c, exact int32
+__device__ inline int dot2(v2s a, v2s b, int c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
+
+// LDS byte pairs. The window columns start at an arbitrary byte of the tile, and unaligned
+// ds_read_u16/b32 stall the LDS pipeline (SQ_LDS_UNALIGNED_STALL ~ its whole active time when
+// measured), while the compiler fuses adjacent byte loads into exactly those. So the tiles are
+// read with explicit ds_read_u8 (d16_hi loads do not keep the other half with SRAM-ECC on, so
+// a pair costs two loads and one v_lshl_or). The loads are issued without waiting;
+// lds_fence() must run before the registers are used.
+__device__ inline uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)((const SVO_LDS(uint8_t)*)p);
+}
+template <int OFF>
+__device__ inline int lds_byte_nowait(uint32_t addr) {
+    int r;
+    asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ inline void lds_fence(int (&r)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(r[i]));
+}
+template <int STRIDE, int OFF, int... U>
+__device__ inline void lds_col_impl(uint32_t a, int* r, std::integer_sequence<int, U...>) {
+    ((r[U] = lds_byte_nowait<U * STRIDE + OFF>(a)), ...);
+}
+template <int STRIDE, int OFF, int N>
+__device__ inline void lds_col_nowait(uint32_t a, int (&r)[N]) {
+    lds_col_impl<STRIDE, OFF>(a, r, std::make_integer_sequence<int, N>{});
+}
+// r[u] = (tile[u*STRIDE + LO], tile[u*STRIDE + HI]) as int16 pairs, u = 0..N-1 (waits for the loads)
+template <int STRIDE, int LO, int HI, int N>
+__device__ inline void lds_pairs(uint32_t a, int (&r)[N]) {
+    int hi[N];
+    lds_col_nowait<STRIDE, LO>(a, r);
+    lds_col_nowait<STRIDE, HI>(a, hi);
+    lds_fence(r);
+    lds_fence(hi);
+#pragma unroll
+    for (int u = 0; u < N; u++) r[u] |= hi[u] << 16;
+}
 
 // exact 64-bit sum of per-thread int32 partials over the workgroup
 // (DPP row adds per wave, waves combined through LDS), same value in every thread
@@ -38,8 +95,10 @@ __device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], l
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         const long long w = wave_sum_i32_to_i64(v[k]);
-        if ((threadIdx.x & 63) == 0) s_part[wave][k] = w;
+        if (KLT_WAVES == 1) out[k] = w;
+        else if ((threadIdx.x & 63) == 0) s_part[wave][k] = w;
     }
+    if (KLT_WAVES == 1) return;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; k++) {
@@ -51,36 +110,85 @@ __device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], l
     __syncthreads();
 }
 
-#define SVO_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
-// every product in the window loops has operands below 2^23 in magnitude (pixels < 2^8,
-// weights <= 2^14, derivatives < 2^13, differences < 2^14): full-rate 24-bit multiplies
-// instead of the quarter-rate 32-bit v_mul_lo_u32
+// every product in the window loops has operands below 2^23 in magnitude: full-rate 24-bit multiplies
 #define M24(a, b) __mul24((a), (b))
 
 __device__ inline int cv_round(float v) { return (int)rintf(v); }
 __device__ inline int cv_floor(float v) { return (int)floorf(v); }
 
+struct LkWeights { v2s top, bot; };
+// the four 14-bit bilinear weights of calcOpticalFlowPyrLK for the fractions (fa, fb)
+__device__ inline LkWeights lk_weights(float fa, float fb) {
+    const int W_BITS = 14;
+    const int iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+    const int iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
+    const int iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
+    const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    return LkWeights{as_v2s(pack16(iw00, iw01)), as_v2s(pack16(iw10, iw11))};
+}
+
+// stage rows [y0, y0+rows) x columns [x0, x0+4*nq) of `im` into an LDS tile with row stride `ls`
+// (x0 % 4 == 0). Dword loads when the rectangle lies inside the image and the image is dword
+// aligned, else one byte per (row, column) with BORDER_REFLECT_101 addressing.
+template <int LS, int MAXROWS>
+__device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int y0, int nq, int rows) {
+    const int tid = threadIdx.x;
+    const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * nq <= im.w && y0 + rows <= im.h &&
+                      (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
+    if (fast) {
+        constexpr int RPP = KLT_THREADS / 16;                        // rows per pass, 16 dword lanes per row
+        constexpr int NP = (MAXROWS + RPP - 1) / RPP;
+        const int c4 = tid & 15, r0 = tid >> 4;
+        if (c4 < nq) {
+            const uint8_t* g = im.data + M24(y0 + r0, im.stride) + x0 + 4 * c4;
+            uint32_t v[NP];
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+                v[u] = (r0 + u * RPP < rows) ? *reinterpret_cast<const uint32_t*>(g + M24(u * RPP, im.stride)) : 0u;
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+                if (r0 + u * RPP < rows) *reinterpret_cast<uint32_t*>(&tile[(r0 + u * RPP) * LS + 4 * c4]) = v[u];
+        }
+    } else {
+        const int tcol = tid & 63, trow0 = tid >> 6;
+        if (tcol < 4 * nq) {
+            const int gx = reflect101(x0 + tcol, im.w);
+            for (int r = trow0 * 8; r < rows; r += 8 * KLT_WAVES) {      // 8 independent loads in flight
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int gy = reflect101(y0 + min(r + u, rows - 1), im.h);
+                    v[u] = im.data[M24(gy, im.stride) + gx];            // offsets < 2^31
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (r + u < rows) tile[(r + u) * LS + tcol] = v[u];
+            }
+        }
+    }
+}
+
+// CW: threads per window row (32 when w+1 <= 32, else 64); a thread owns column lc and
+// the RPT consecutive rows starting at lr*RPT.
+template <int CW>
 __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* __restrict__ args) {
+    constexpr int NG = KLT_THREADS / CW;                               // row groups
+    constexpr int ROWS = CW == 32 ? 32 : KLT_DW;                        // tap rows to cover
+    constexpr int RPT = (((ROWS + NG - 1) / NG) + 1) & ~1;              // even: rows are kept as pairs
+    constexpr int NPAIR = RPT / 2;
     const KltArgs& a = args[blockIdx.y];
     const int n = *a.n_ptr;
     const int kp = blockIdx.x;
     if (kp >= n) return;
-    const int lane = threadIdx.x;          // thread index in the workgroup
+    const int tid = threadIdx.x;
     const int win = a.win;
     const int RW = win + 3, DW = win + 1, TJ = DW + 2 * KLT_MARGIN;
-    // thread -> (row offset, column): a row takes half a wave when it fits, else a whole wave
-    const bool two = DW <= 32;
-    const int lc = two ? (lane & 31) : (lane & 63);
-    const int lr = two ? (lane >> 5) : (lane >> 6);
-    const int rstep = two ? KLT_THREADS / 32 : KLT_THREADS / 64;
-    // tile loads: one thread per column, the rows split over the threads sharing that column
-    const int tcol = lane & 63, trow0 = lane >> 6;
+    const int lc = tid & (CW - 1), lr = tid / CW;
+    const int y0 = lr * RPT;
 
-    __shared__ uint8_t s_I[KLT_RW * KLT_RW];
-    __shared__ int s_d[KLT_DW * KLT_DW];          // packed (dx, dy) int16
-    __shared__ short s_Iw[KLT_MAX_WIN * KLT_MAX_WIN];
-    __shared__ int s_dIw[KLT_MAX_WIN * KLT_MAX_WIN];
-    __shared__ uint8_t s_J[KLT_TJ * KLT_TJ];
+    __shared__ __attribute__((aligned(16))) uint8_t s_I[KLT_RROWS * KLT_RS];
+    __shared__ int s_d[(KLT_DW + 1) * KLT_DW];    // packed (dx, dy) int16; + one slack row
+    __shared__ __attribute__((aligned(16))) uint8_t s_J[KLT_TJROWS * KLT_TJS];
     __shared__ long long s_part[KLT_WAVES][4];
 
     const int kfid = a.kf_id ? a.kf_id[kp] : 0;
@@ -98,7 +206,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         const svo_kp2d q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
         nx = q.x; ny = q.y;
         ref = kf.kps2d[a.kp_index[kp]];
-        if (lane == 0) {
+        if (tid == 0) {
             a.proj_out[kp] = q;
             if (a.ref_out) a.ref_out[kp] = ref;
         }
@@ -116,6 +224,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     epsilon *= epsilon;
     int status = 1;
     float err = 0;
+    const bool col_on = lc < win;
 
     for (int level = maxLevel; level >= 0; level--) {
         const ImgView I = kf.lk[level];
@@ -132,66 +241,73 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             if (level == 0) { status = 0; err = 0; }
             continue;
         }
-        float fa = prevx - iprevx, fb = prevy - iprevy;
-        int iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-        int iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
-        int iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
-        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        LkWeights wt = lk_weights(prevx - iprevx, prevy - iprevy);
 
         __syncthreads();
-        // (w+3)^2 tile of I around the window, rows iprevy-1 .., reflect-101
-        if (tcol < RW) {
-            const int gx = reflect101(iprevx - 1 + tcol, I.w);
-            for (int r0 = trow0 * 8; r0 < RW; r0 += 8 * KLT_WAVES) {   // 8 independent loads in flight
-                uint8_t v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int gy = reflect101(iprevy - 1 + min(r0 + u, RW - 1), I.h);
-                    v[u] = I.data[M24(gy, I.stride) + gx];   // images are < 2^24 x 2^24, offsets < 2^31
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (r0 + u < RW) s_I[(r0 + u) * KLT_RW + tcol] = v[u];
-            }
-        }
+        // (w+3)^2 tile of I around the window: rows iprevy-1 .., columns from the dword boundary left of iprevx-1
+        const int ix0 = (iprevx - 1) & ~3;
+        const int ox = iprevx - 1 - ix0;                 // 0..3
+        stage_tile<KLT_RS, KLT_RROWS>(s_I, I, ix0, iprevy - 1, (ox + RW + 3) >> 2, RW);
         __syncthreads();
-        // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions; 0 outside the image
+
+        // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions, sliding down the thread's rows:
+        // hd = p[+1]-p[-1], hs = 3(p[-1]+p[+1]) + 10 p[0] per tile row; dx = 3(hd_0+hd_2) + 10 hd_1,
+        // dy = hs_2 - hs_0. Zero outside the image.
         if (lc < DW) {
             const int gx = iprevx + lc;
             const bool xin = (unsigned)gx < (unsigned)I.w;
-            for (int r = lr; r < DW; r += rstep) {
-                const int gy = iprevy + r;
-                int packed = 0;
-                if (xin && (unsigned)gy < (unsigned)I.h) {
-                    const uint8_t* p0 = &s_I[r * KLT_RW + lc];      // row gy-1, col gx-1
-                    const uint8_t* p1 = p0 + KLT_RW;
-                    const uint8_t* p2 = p1 + KLT_RW;
-                    const int t0m = M24(p0[0] + p2[0], 3) + M24(p1[0], 10), t0p = M24(p0[2] + p2[2], 3) + M24(p1[2], 10);
-                    const int t1m = p2[0] - p0[0], t1c = p2[1] - p0[1], t1p = p2[2] - p0[2];
-                    const int dx = t0p - t0m;
-                    const int dy = M24(t1p + t1m, 3) + M24(t1c, 10);
-                    packed = (dx & 0xffff) | (dy << 16);
-                }
-                s_d[r * KLT_DW + lc] = packed;
+            const uint32_t pcol = lds_addr(&s_I[y0 * KLT_RS + ox + lc]);
+            int p02[RPT + 2], p1[RPT + 2];
+            lds_col_nowait<KLT_RS, 1>(pcol, p1);
+            lds_pairs<KLT_RS, 0, 2>(pcol, p02);
+            lds_fence(p1);
+            const v2s kd = as_v2s(pack16(-1, 1)), ks = as_v2s(pack16(3, 3));
+            int hd0 = dot2(as_v2s(p02[0]), kd, 0), hs0 = dot2(as_v2s(p02[0]), ks, M24(p1[0], 10));
+            int hd1 = dot2(as_v2s(p02[1]), kd, 0), hs1 = dot2(as_v2s(p02[1]), ks, M24(p1[1], 10));
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                const int r = y0 + u;
+                const int hd2 = dot2(as_v2s(p02[u + 2]), kd, 0), hs2 = dot2(as_v2s(p02[u + 2]), ks, M24(p1[u + 2], 10));
+                const int dx = M24(hd0 + hd2, 3) + M24(hd1, 10);
+                const int dy = hs2 - hs0;
+                if (r < DW) s_d[r * KLT_DW + lc] = (xin && (unsigned)(iprevy + r) < (unsigned)I.h) ? pack16(dx, dy) : 0;
+                hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
             }
         }
         __syncthreads();
-        // template + covariance of derivatives (per-lane int32 partials: <= 18 pixels each)
+
+        // template of the thread's rows (registers) + covariance of the derivatives
+        // (per-thread int32 partials: <= 36 pixels, each product < 2^24)
+        int tIw[NPAIR], tIx[NPAIR], tIy[NPAIR];
         int a11 = 0, a12 = 0, a22 = 0;
-        if (lc < win) {
-            for (int y = lr; y < win; y += rstep) {
-                const uint8_t* src = &s_I[(y + 1) * KLT_RW + lc + 1];
-                const int* ds = &s_d[y * KLT_DW + lc];
-                const int ival = SVO_DESCALE(M24(src[0], iw00) + M24(src[1], iw01) + M24(src[KLT_RW], iw10) +
-                                             M24(src[KLT_RW + 1], iw11), W_BITS - 5);
-                const int d00 = ds[0], d01 = ds[1], d10 = ds[KLT_DW], d11 = ds[KLT_DW + 1];
-                const int ixval = SVO_DESCALE(M24((int)(short)d00, iw00) + M24((int)(short)d01, iw01) +
-                                              M24((int)(short)d10, iw10) + M24((int)(short)d11, iw11), W_BITS);
-                const int iyval = SVO_DESCALE(M24(d00 >> 16, iw00) + M24(d01 >> 16, iw01) +
-                                              M24(d10 >> 16, iw10) + M24(d11 >> 16, iw11), W_BITS);
-                s_Iw[y * KLT_MAX_WIN + lc] = (short)ival;
-                s_dIw[y * KLT_MAX_WIN + lc] = (ixval & 0xffff) | (iyval << 16);
+        {
+            const int lcs = col_on ? lc : 0;                             // keep idle columns in bounds
+            // tile row y+1 holds image row iprevy+y
+            int ipr[RPT + 1];
+            lds_pairs<KLT_RS, 0, 1>(lds_addr(&s_I[(y0 + 1) * KLT_RS + ox + lcs + 1]), ipr);
+            const int* dcol = &s_d[y0 * KLT_DW + lcs];
+            int d0 = dcol[0], d1 = dcol[1];
+            v2s dxp = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x05040100u));
+            v2s dyp = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
+            int iv[2], ixv[2], iyv[2];
+#pragma unroll
+            for (int u = 0; u < RPT; u++) {
+                const int y = y0 + u;
+                d0 = dcol[(u + 1) * KLT_DW]; d1 = dcol[(u + 1) * KLT_DW + 1];
+                const v2s dxp1 = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x05040100u));
+                const v2s dyp1 = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
+                int ival = dot2(as_v2s(ipr[u]), wt.top, dot2(as_v2s(ipr[u + 1]), wt.bot, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                int ixval = dot2(dxp, wt.top, dot2(dxp1, wt.bot, 1 << (W_BITS - 1))) >> W_BITS;
+                int iyval = dot2(dyp, wt.top, dot2(dyp1, wt.bot, 1 << (W_BITS - 1))) >> W_BITS;
+                if (!(col_on && y < win)) { ival = 0; ixval = 0; iyval = 0; }
                 a11 += M24(ixval, ixval); a12 += M24(ixval, iyval); a22 += M24(iyval, iyval);
+                iv[u & 1] = ival; ixv[u & 1] = ixval; iyv[u & 1] = iyval;
+                if (u & 1) {
+                    tIw[u >> 1] = pack16(iv[0], iv[1]);
+                    tIx[u >> 1] = pack16(ixv[0], ixv[1]);
+                    tIy[u >> 1] = pack16(iyv[0], iyv[1]);
+                }
+                dxp = dxp1; dyp = dyp1;
             }
         }
         long long sA[3];
@@ -214,28 +330,23 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         float prevDx = 0, prevDy = 0;
         int tx0 = 0, ty0 = 0;
         bool have_tile = false;
+        const int TW = (TJ + 3 + 3) & ~3;            // tile columns: covers the 6 px margin from any dword phase
 
-        // stage the search tile [tx0, tx0+TJ) x [ty0, ty0+TJ) around (cx, cy)
+        // stage the search tile [tx0, tx0+TW) x [ty0, ty0+TJ) around the window at (cx, cy)
         auto load_tile = [&](int cx, int cy) {
-            tx0 = cx - KLT_MARGIN; ty0 = cy - KLT_MARGIN;
+            tx0 = (cx - KLT_MARGIN) & ~3; ty0 = cy - KLT_MARGIN;
             __syncthreads();
-            if (tcol < TJ) {
-                const int gx = reflect101(tx0 + tcol, J.w);
-                for (int r0 = trow0 * 8; r0 < TJ; r0 += 8 * KLT_WAVES) {
-                    uint8_t v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int gy = reflect101(ty0 + min(r0 + u, TJ - 1), J.h);
-                        v[u] = J.data[M24(gy, J.stride) + gx];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (r0 + u < TJ) s_J[(r0 + u) * KLT_TJ + tcol] = v[u];
-                }
-            }
+            stage_tile<KLT_TJS, KLT_TJROWS>(s_J, J, tx0, ty0, TW >> 2, TJ);
             __syncthreads();
             have_tile = true;
         };
+        // J(x+d) - I(x) of the thread's row pair k for the window whose rows were read into jr
+        auto row_pair_diff = [&](const int (&jr)[RPT + 1], const LkWeights& w, int k) -> v2s {
+            const int v0 = dot2(as_v2s(jr[2 * k]), w.top, dot2(as_v2s(jr[2 * k + 1]), w.bot, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const int v1 = dot2(as_v2s(jr[2 * k + 1]), w.top, dot2(as_v2s(jr[2 * k + 2]), w.bot, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            return as_v2s(pack16(v0, v1)) - as_v2s(tIw[k]);
+        };
+        const uint32_t jcol = lds_addr(&s_J[y0 * KLT_TJS + lc]);
 
         for (int j = 0; j < 30; j++) {
             const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
@@ -243,24 +354,18 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 if (level == 0) status = 0;
                 break;
             }
-            if (!have_tile || inextx < tx0 || inexty < ty0 || inextx + DW > tx0 + TJ || inexty + DW > ty0 + TJ)
+            if (!have_tile || inextx < tx0 || inexty < ty0 || inextx + DW > tx0 + TW || inexty + DW > ty0 + TJ)
                 load_tile(inextx, inexty);
-            fa = nextx - inextx; fb = nexty - inexty;
-            iw00 = cv_round((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-            iw01 = cv_round(fa * (1.f - fb) * (1 << W_BITS));
-            iw10 = cv_round((1.f - fa) * fb * (1 << W_BITS));
-            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            wt = lk_weights(nextx - inextx, nexty - inexty);
             int b1 = 0, b2 = 0;
-            if (lc < win) {
-                const uint8_t* jbase = &s_J[(inexty - ty0) * KLT_TJ + (inextx - tx0) + lc];
-                for (int y = lr; y < win; y += rstep) {
-                    const uint8_t* jp = jbase + y * KLT_TJ;
-                    const int diff = SVO_DESCALE(M24(jp[0], iw00) + M24(jp[1], iw01) + M24(jp[KLT_TJ], iw10) +
-                                                 M24(jp[KLT_TJ + 1], iw11), W_BITS - 5) -
-                                     (int)s_Iw[y * KLT_MAX_WIN + lc];
-                    const int dI = s_dIw[y * KLT_MAX_WIN + lc];
-                    b1 += M24(diff, (int)(short)dI);
-                    b2 += M24(diff, dI >> 16);
+            if (col_on) {
+                int jr[RPT + 1];
+                lds_pairs<KLT_TJS, 0, 1>(jcol + (inexty - ty0) * KLT_TJS + (inextx - tx0), jr);
+#pragma unroll
+                for (int k = 0; k < NPAIR; k++) {
+                    const v2s diff = row_pair_diff(jr, wt, k);
+                    b1 = dot2(diff, as_v2s(tIx[k]), b1);      // rows outside the window have Ix = Iy = 0
+                    b2 = dot2(diff, as_v2s(tIy[k]), b2);
                 }
             }
             long long sB[2];
@@ -289,22 +394,18 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 status = 0;
                 continue;
             }
-            if (!have_tile || inx < tx0 || iny < ty0 || inx + DW > tx0 + TJ || iny + DW > ty0 + TJ)
+            if (!have_tile || inx < tx0 || iny < ty0 || inx + DW > tx0 + TW || iny + DW > ty0 + TJ)
                 load_tile(inx, iny);
-            const float aa = npx - inx, bb = npy - iny;
-            iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
-            iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
-            iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
-            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            wt = lk_weights(npx - inx, npy - iny);
             int e = 0;
-            if (lc < win) {
-                const uint8_t* jbase = &s_J[(iny - ty0) * KLT_TJ + (inx - tx0) + lc];
-                for (int y = lr; y < win; y += rstep) {
-                    const uint8_t* jp = jbase + y * KLT_TJ;
-                    const int diff = SVO_DESCALE(M24(jp[0], iw00) + M24(jp[1], iw01) + M24(jp[KLT_TJ], iw10) +
-                                                 M24(jp[KLT_TJ + 1], iw11), W_BITS - 5) -
-                                     (int)s_Iw[y * KLT_MAX_WIN + lc];
-                    e += diff < 0 ? -diff : diff;
+            if (col_on) {
+                int jr[RPT + 1];
+                lds_pairs<KLT_TJS, 0, 1>(jcol + (iny - ty0) * KLT_TJS + (inx - tx0), jr);
+#pragma unroll
+                for (int k = 0; k < NPAIR; k++) {
+                    const v2s diff = row_pair_diff(jr, wt, k);
+                    if (y0 + 2 * k < win) e += abs((int)diff.x);
+                    if (y0 + 2 * k + 1 < win) e += abs((int)diff.y);
                 }
             }
             long long sE[1];
@@ -317,7 +418,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         }
     }
 
-    if (lane == 0) {
+    if (tid == 0) {
         a.cur_pts[kp] = svo_kp2d{nx, ny};
         a.status[kp] = (uint8_t)status;
         a.err[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
@@ -325,9 +426,11 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
 }
 
 void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream) {
-    (void)win;
     if (max_n <= 0) return;
-    hipLaunchKernelGGL(klt_track_kernel, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
+    if (win + 1 <= 32)
+        hipLaunchKernelGGL(klt_track_kernel<32>, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
+    else
+        hipLaunchKernelGGL(klt_track_kernel<64>, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
 }
 
 }  // namespace svo
