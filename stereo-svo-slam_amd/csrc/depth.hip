@@ -34,112 +34,46 @@ __device__ inline uint32_t load_u8x4(const ImgView& im, int y, int x, int valid)
     return v;
 }
 
-constexpr int SSD_MAX_WIN = 36;                 // template edge (window <= 35)
-constexpr int SSD_NOFF = 4;                     // vertically adjacent offsets per work item
-constexpr int SSD_T_STRIDE = 12;                // dwords (48 B: aligned 16 B reads)
-constexpr int SSD_T_PAD = SSD_NOFF - 1;         // zero rows before the template
-constexpr int SSD_T_ROWS = SSD_MAX_WIN + 2 * SSD_T_PAD + 4;
-constexpr int SSD_R_STRIDE = 112;               // bytes per search-region row (>= 35+64+pad)
-constexpr int SSD_R_ROWS = SSD_MAX_WIN + 16 + SSD_NOFF + 4;
-constexpr int SSD_MAX_MATCH = 65 * 17;
+constexpr int SSD_MAX_WIN = 35;                 // template edge
+constexpr int SSD_MAX_MH = 17, SSD_MAX_MW = 65; // match map: (2*search_y+1) x (search_x+1)
+constexpr int SSD_T_STRIDE = 96;                // bytes per padded template row: 16 zeros | row | zeros
+constexpr int SSD_R_STRIDE = 144;               // bytes per search-region row (36 dwords: conflict-free b128 rows)
+constexpr int SSD_R_ROWS = SSD_MAX_WIN + SSD_MAX_MH;   // 52
+constexpr int SSD_W_STRIDE = 100;               // ints per row of the column sums
+constexpr int SSD_MAX_MATCH = SSD_MAX_MW * SSD_MAX_MH;
 constexpr int SSD_THREADS = 256;
 
-// C1. One workgroup per keypoint. The template (zero padded to whole dwords,
-// with zero rows above and below) and the search region sit in LDS. A work
-// item is 4 vertically adjacent offsets (k0..k0+3, j): every search-region row
-// is read once (TW4+1 dwords, funnel-shifted to the column phase j&3 with
-// v_alignbyte), squared once (v_dot4_u32_u8 with itself) and multiplied
-// against the 4 template rows it meets (v_dot4_u32_u8); the template rows
-// slide through registers (one broadcast LDS read per step), so
-// SSD = sum a^2 - 2 sum a*t + sum t^2 costs ~0.4 instructions per pixel pair
-// and stays an exact integer. TW4 = dwords per template row (6, 8 or 9).
-template <int TW4>
-__device__ inline void ssd_load_trow(const uint32_t* s_t, int row, uint32_t (&t)[TW4]) {
-    const uint4* t4 = reinterpret_cast<const uint4*>(&s_t[(row + SSD_T_PAD) * SSD_T_STRIDE]);
-    uint32_t tv[12];
-    *reinterpret_cast<uint4*>(&tv[0]) = t4[0];
-    if (TW4 > 4) *reinterpret_cast<uint4*>(&tv[4]) = t4[1];
-    if (TW4 > 8) *reinterpret_cast<uint4*>(&tv[8]) = t4[2];
-#pragma unroll
-    for (int d = 0; d < TW4; d++) t[d] = tv[d];
-}
+typedef int ssd_v4i __attribute__((ext_vector_type(4)));
 
-template <int TW4, bool ANYW>
-__device__ inline void ssd_items(const uint32_t* s_t, const uint8_t* s_r, int* s_m, uint32_t stt,
-                                 int tw, int th, int mw, int mh) {
-    const int tid = threadIdx.x;
-    // !ANYW: tw fills exactly TW4 dwords, only the last one is partial.
-    // ANYW (windows clamped at the image border): a mask per dword.
-    const int rem = tw - 4 * (TW4 - 1);
-    const uint32_t last_mask = (rem >= 4 || rem <= 0) ? 0xFFFFFFFFu : ((1u << (8 * rem)) - 1u);
-    uint32_t msk[TW4];
-#pragma unroll
-    for (int d = 0; d < TW4; d++) {
-        const int rd = tw - 4 * d;
-        msk[d] = rd >= 4 ? 0xFFFFFFFFu : (rd <= 0 ? 0u : ((1u << (8 * rd)) - 1u));
-    }
-    const int ngroups = (mh + SSD_NOFF - 1) / SSD_NOFF;
-    const int nsteps = (th + SSD_NOFF - 1 + 3) & ~3;           // whole rotations of the 4 row registers
-    for (int item = tid; item < ngroups * mw; item += SSD_THREADS) {
-        const int kg = item / mw, j = item - kg * mw;
-        const int k0 = kg * SSD_NOFF;
-        const unsigned shift = (unsigned)(j & 3);
-        const uint32_t* rbase = reinterpret_cast<const uint32_t*>(s_r) + (j >> 2) + k0 * (SSD_R_STRIDE / 4);
-        uint32_t sab0 = 0, sab1 = 0, sab2 = 0, sab3 = 0, saa0 = 0, saa1 = 0, saa2 = 0, saa3 = 0;
-        uint32_t ta[TW4], tb[TW4], tc[TW4], td[TW4];            // template rows st, st-1, st-2, st-3
-#pragma unroll
-        for (int d = 0; d < TW4; d++) { ta[d] = 0; tb[d] = 0; tc[d] = 0; td[d] = 0; }
-
-        // one search-region row against the template rows (t0 newest .. t3 oldest)
-        auto step = [&](int st, uint32_t (&t0)[TW4], const uint32_t (&t1)[TW4],
-                        const uint32_t (&t2)[TW4], const uint32_t (&t3)[TW4]) {
-            ssd_load_trow<TW4>(s_t, st, t0);
-            const uint32_t* rr = rbase + st * (SSD_R_STRIDE / 4);
-            uint32_t w[TW4 + 1];
-#pragma unroll
-            for (int d = 0; d <= TW4; d++) w[d] = rr[d];
-            uint32_t rowsq = 0;
-#pragma unroll
-            for (int d = 0; d < TW4; d++) {
-                uint32_t v = __builtin_amdgcn_alignbyte(w[d + 1], w[d], shift);   // column phase j & 3
-                if (ANYW) v &= msk[d];
-                else if (d == TW4 - 1) v &= last_mask;
-                rowsq = __builtin_amdgcn_udot4(v, v, rowsq, false);
-                sab0 = __builtin_amdgcn_udot4(v, t0[d], sab0, false);
-                sab1 = __builtin_amdgcn_udot4(v, t1[d], sab1, false);
-                sab2 = __builtin_amdgcn_udot4(v, t2[d], sab2, false);
-                sab3 = __builtin_amdgcn_udot4(v, t3[d], sab3, false);
-            }
-            saa0 += (st < th) ? rowsq : 0u;
-            saa1 += (st >= 1 && st - 1 < th) ? rowsq : 0u;
-            saa2 += (st >= 2 && st - 2 < th) ? rowsq : 0u;
-            saa3 += (st >= 3 && st - 3 < th) ? rowsq : 0u;
-        };
-        for (int st = 0; st < nsteps; st += 4) {
-            step(st, ta, tb, tc, td);
-            step(st + 1, td, ta, tb, tc);
-            step(st + 2, tc, td, ta, tb);
-            step(st + 3, tb, tc, td, ta);
-        }
-        if (k0 + 0 < mh) s_m[(k0 + 0) * mw + j] = (int)(saa0 + stt - 2u * sab0);
-        if (k0 + 1 < mh) s_m[(k0 + 1) * mw + j] = (int)(saa1 + stt - 2u * sab1);
-        if (k0 + 2 < mh) s_m[(k0 + 2) * mw + j] = (int)(saa2 + stt - 2u * sab2);
-        if (k0 + 3 < mh) s_m[(k0 + 3) * mw + j] = (int)(saa3 + stt - 2u * sab3);
-    }
-}
-
+// C1. One workgroup (4 waves) per keypoint. cv::matchTemplate(TM_SQDIFF) is
+//   SSD[k][j] = sum_w R^2 - 2 sum_w R*T + sum T^2   over the window w at offset (k, j),
+// exact in integers, and it is invariant to subtracting 128 from every pixel, so both images
+// are staged as signed bytes (x ^ 0x80).
+//  * The cross term is a correlation: 0.76 M multiply-adds per keypoint at the C2 settings,
+//    the one place of this path with GEMM-class arithmetic. It runs on the matrix cores as a
+//    Toeplitz product, one v_mfma_i32_16x16x64_i8 per template row r and 16-column block j0:
+//        D[k][n] += sum_x A[k][x] * B[x][n],  A[k][x] = R[k + r][j0 + x]  (aligned 16 B / lane),
+//                                             B[x][n] = T[r][x - n]       (0 outside the row),
+//    so D[k][n] accumulates sum_{r,c} R[k+r][j0+n+c] T[r][c] over the th rows. Rows k >= mh and
+//    columns j >= mw of D are computed and dropped. A wave owns a (16-row, 16-column) block of
+//    the match map; B is rebuilt per row from the zero-padded template (5 dwords + v_alignbyte).
+//    Any k-order inside the instruction is fine as long as A and B agree: lane l holds bytes
+//    16*(l>>4) .. +15 of its row / column for both operands.
+//  * sum_w R^2: sliding window sums, columns first (one thread per region column), then rows.
+//  * argmin (first minimum in row-major order) and the tie-averaged column of :313-323 as before.
 __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
     const SsdArgs& a = args[blockIdx.y];
     if (a.enable && !*a.enable) return;
     const int n = *a.n_ptr;
     const int kp = a.first + (a.first_ptr ? *a.first_ptr : 0) + (int)blockIdx.x;
     if (kp >= n) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_t[SSD_T_ROWS * SSD_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[(SSD_MAX_WIN + 1) * SSD_T_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t s_r[SSD_R_ROWS * SSD_R_STRIDE];
+    __shared__ int s_w[SSD_MAX_MH * SSD_W_STRIDE];
     __shared__ int s_m[SSD_MAX_MATCH];
-    __shared__ uint32_t s_tt[SSD_MAX_WIN];
+    __shared__ int s_tt[4];
     __shared__ unsigned long long s_key[SSD_THREADS / 64];
     __shared__ int s_sum[SSD_THREADS / 64], s_cnt[SSD_THREADS / 64];
 
@@ -161,48 +95,128 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     if (a.clamp_half && (x12 <= 0 || y12 <= 0 || x11 >= cols - 1 || y11 >= rows - 1)) skip = true;
     if (a.clamp_half && (x22 <= 0 || y22 <= 0 || x21 >= cols - 1 || y21 >= rows - 1)) skip = true;
     if (tw <= 0 || th <= 0 || mw <= 0 || mh <= 0) skip = true;
-    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || rw > SSD_R_STRIDE - 12 || rh > SSD_R_ROWS - SSD_NOFF - 4 ||
-        mw * mh > SSD_MAX_MATCH)
+    if (tw > SSD_MAX_WIN || th > SSD_MAX_WIN || mw > SSD_MAX_MW || mh > SSD_MAX_MH || rw > SSD_W_STRIDE ||
+        rh > SSD_R_ROWS)
         skip = true;  // the host validates window sizes; never taken with valid settings
     if (skip) {
         if (tid == 0) a.disparity[kp] = -1.0f;
         return;
     }
 
-    // ---- stage template (zero rows around it, zero beyond tw) and search region (zero outside)
-    for (int i = tid; i < SSD_T_ROWS * SSD_T_STRIDE; i += SSD_THREADS) {
-        const int r = i / SSD_T_STRIDE - SSD_T_PAD, d = i % SSD_T_STRIDE;
+    // ---- stage: template rows as [16 zero bytes | row ^ 0x80 | zeros], search region ^ 0x80
+    for (int i = tid; i < (SSD_MAX_WIN + 1) * (SSD_T_STRIDE / 4); i += SSD_THREADS) {
+        const int r = i / (SSD_T_STRIDE / 4), d = i % (SSD_T_STRIDE / 4);
+        const int c = 4 * (d - 4);                        // template column of the dword's first byte
         uint32_t v = 0;
-        if (r >= 0 && r < th && 4 * d < tw)
-            v = load_u8x4(a.left, y11 + r, x11 + 4 * d, tw - 4 * d);
-        s_t[i] = v;
+        if (r < th && c >= 0 && c < tw) {
+            const int valid = tw - c;
+            const uint32_t vm = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
+            v = load_u8x4(a.left, y11 + r, x11 + c, valid) ^ (0x80808080u & vm);
+        }
+        reinterpret_cast<uint32_t*>(s_t)[i] = v;
     }
     for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 4); i += SSD_THREADS) {
         const int r = i / (SSD_R_STRIDE / 4), d = i % (SSD_R_STRIDE / 4);
         uint32_t v = 0;
         if (r < rh && 4 * d < rw)
-            v = load_u8x4(a.right, y21 + r, x21 + 4 * d, rw - 4 * d);
+            v = load_u8x4(a.right, y21 + r, x21 + 4 * d, rw - 4 * d) ^ 0x80808080u;
         reinterpret_cast<uint32_t*>(s_r)[i] = v;
     }
     __syncthreads();
-    if (tid < th) {
-        uint32_t tt = 0;
+
+    // ---- sum T^2 (wave 3) and the column sums W[k][x] = sum_{r<th} R[k+r][x]^2 (one thread per column)
+    if (wave == 3) {
+        int tt = 0;
+        if (lane < th) {
+            const uint32_t* trow = reinterpret_cast<const uint32_t*>(s_t + lane * SSD_T_STRIDE) + 4;
 #pragma unroll
-        for (int d = 0; d < 9; d++) {
-            const uint32_t t = s_t[(tid + SSD_T_PAD) * SSD_T_STRIDE + d];
-            tt = __builtin_amdgcn_udot4(t, t, tt, false);
+            for (int d = 0; d < 9; d++) tt = __builtin_amdgcn_sdot4((int)trow[d], (int)trow[d], tt, false);
         }
-        s_tt[tid] = tt;
+        tt = wave_sum_dpp_i(tt);
+        if (lane == 0) s_tt[0] = tt;
+    }
+    if (tid < rw) {
+        const int8_t* col = reinterpret_cast<const int8_t*>(s_r) + tid;
+        int sq = 0;
+        for (int r = 0; r < th; r++) {
+            const int v = col[r * SSD_R_STRIDE];
+            sq += __mul24(v, v);
+        }
+        s_w[tid] = sq;
+        for (int k = 1; k < mh; k++) {
+            const int vn = col[(k + th - 1) * SSD_R_STRIDE], vo = col[(k - 1) * SSD_R_STRIDE];
+            sq += __mul24(vn, vn) - __mul24(vo, vo);
+            s_w[k * SSD_W_STRIDE + tid] = sq;
+        }
+    }
+
+    // ---- cross term on the matrix cores: wave -> (row block, column block) of the match map
+    const int n_jb = (mw + 15) >> 4, n_mb = (mh + 15) >> 4;
+    const int fm = lane & 15, fh = lane >> 4;        // fragment row / column and 16-byte k slice
+    constexpr int SSD_SLOTS = 3;                     // <= 2 x 5 blocks over 4 waves
+    ssd_v4i acc[SSD_SLOTS] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int task_of[SSD_SLOTS] = {-1, -1, -1};
+    {
+        int slot = 0;
+        for (int task = wave; task < n_jb * n_mb && slot < SSD_SLOTS; task += SSD_THREADS / 64, slot++) {
+            task_of[slot] = task;
+            const int mb = task / n_jb, jb = task - mb * n_jb;
+            // B: bytes [16 + 16 fh - fm, +16) of the padded template row
+            const int o = 16 + 16 * fh - fm;
+            const uint32_t* tb = reinterpret_cast<const uint32_t*>(s_t) + (o >> 2);
+            const unsigned sh = (unsigned)(o & 3);
+            const uint8_t* ab = s_r + (16 * jb + 16 * fh);
+            const int arow = 16 * mb + fm;
+            ssd_v4i c = {0, 0, 0, 0};
+            for (int r = 0; r < th; r++) {
+                const uint32_t* t = tb + r * (SSD_T_STRIDE / 4);
+                const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+                ssd_v4i bf;
+                bf.x = (int)__builtin_amdgcn_alignbyte(t1, t0, sh);
+                bf.y = (int)__builtin_amdgcn_alignbyte(t2, t1, sh);
+                bf.z = (int)__builtin_amdgcn_alignbyte(t3, t2, sh);
+                bf.w = (int)__builtin_amdgcn_alignbyte(t4, t3, sh);
+                const ssd_v4i af = *reinterpret_cast<const ssd_v4i*>(ab + min(arow + r, SSD_R_ROWS - 1) * SSD_R_STRIDE);
+                c = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, c, 0, 0, 0);
+            }
+            acc[slot] = c;
+        }
     }
     __syncthreads();
-    uint32_t stt = 0;
-    for (int r = 0; r < th; r++) stt += s_tt[r];
 
-    const int tw4 = (tw + 3) >> 2;
-    if (tw4 == 8) ssd_items<8, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);        // window 29..32
-    else if (tw4 == 9) ssd_items<9, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);   // window 33..36
-    else if (tw4 == 6) ssd_items<6, false>(s_t, s_r, s_m, stt, tw, th, mw, mh);   // window 21..24
-    else ssd_items<9, true>(s_t, s_r, s_m, stt, tw, th, mw, mh);                  // anything else
+    // ---- window sums of R^2: rows of W, 8 sliding segments per map row -> s_m
+    {
+        const int seg_len = (mw + 7) >> 3;
+        if (tid < mh * 8) {
+            const int k = tid >> 3, j0 = (tid & 7) * seg_len, j1 = min(mw, j0 + seg_len);
+            if (j0 < j1) {
+                const int* wrow = &s_w[k * SSD_W_STRIDE];
+                int sq = 0;
+                for (int c = 0; c < tw; c++) sq += wrow[j0 + c];
+                s_m[k * mw + j0] = sq;
+                for (int j = j0 + 1; j < j1; j++) {
+                    sq += wrow[j + tw - 1] - wrow[j - 1];
+                    s_m[k * mw + j] = sq;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int stt = s_tt[0];
+#pragma unroll
+        for (int slot = 0; slot < SSD_SLOTS; slot++) {
+            const int task = task_of[slot];
+            if (task < 0) continue;
+            const int mb = task / n_jb, jb = task - mb * n_jb;
+            const int j = 16 * jb + fm;                     // C/D: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = 16 * mb + 4 * fh + i;
+                if (k < mh && j < mw) s_m[k * mw + j] += stt - 2 * acc[slot][i];
+            }
+        }
+    }
     __syncthreads();
 
     const int nm = mw * mh;

@@ -25,6 +25,12 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <cstdlib>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <functional>
 
 #include "../../include/svo_hip.h"
 #include "svo_tracker.hpp"
@@ -192,6 +198,75 @@ struct Seq {
     double pending_ts = 0;
 };
 
+// Host worker pool for the per-sequence host work of a step (pose filter, argument blocks):
+// sequences are independent, and at 256 sequences the 12-state filter alone (a 12x12 Jacobi SVD
+// per sequence) costs as much host time as the GPU needs for the whole frame. The calling
+// thread takes part; workers sleep between steps.
+class HostPool {
+public:
+    explicit HostPool(int n_workers) {
+        for (int i = 0; i < n_workers; i++) workers_.emplace_back([this] { run(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // fn(i) for i in [0, n), in chunks; returns when all are done
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (workers_.empty() || n < 16) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; next_.store(0); busy_ = (int)workers_.size(); gen_++;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void drain() {
+        for (;;) {
+            const int i0 = next_.fetch_add(kChunk);
+            if (i0 >= n_) break;
+            const int i1 = std::min(n_, i0 + kChunk);
+            for (int i = i0; i < i1; i++) (*fn_)(i);
+        }
+    }
+    void run() {
+        unsigned seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--busy_ == 0) done_.notify_one();
+            }
+        }
+    }
+    static constexpr int kChunk = 4;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, busy_ = 0;
+    unsigned gen_ = 0;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 struct svo_ctx {
@@ -213,6 +288,9 @@ struct svo_ctx {
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
     svo_totals totals;
+    HostPool* pool = nullptr;
+    double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
+    long host_steps = 0;
 };
 
 namespace {
@@ -342,27 +420,29 @@ int new_keyframe_storage(svo_ctx* c, Seq& q, int s, int id) {
 // Deferred: the next frame's pose guess only needs the state BEFORE this update
 // (kf.statePre after its predict() equals the current statePost, dt = 0), so the
 // host runs it while the GPU already works on the next frame.
+static void flush_one(Seq& q) {
+    if (!q.pending) return;
+    q.pending = false;
+    float prev_pose[6];
+    std::memcpy(prev_pose, q.pose, sizeof(prev_pose));
+    std::memcpy(q.pose, q.pending_pose, sizeof(q.pose));
+    const double dt = q.pending_ts - q.ts;
+    const double inv = 1. / dt;
+    float motion[6];
+    for (int i = 0; i < 6; i++) motion[i] = (float)((q.pose[i] - prev_pose[i]) * inv);
+    const float pv[6] = {0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f};
+    const float mv[6] = {1, 1, 1, 1, 1, 1};
+    float filtered[6];
+    q.kf.update(q.pose, motion, pv, mv, 0.0, filtered);
+    std::memcpy(q.pose, filtered, sizeof(q.pose));
+    q.ts = q.pending_ts;
+    svo_pose p;
+    std::memcpy(&p, q.pose, sizeof(p));
+    q.trajectory.push_back(p);
+}
 static void flush_pending(svo_ctx* c) {
-    for (Seq& q : c->seqs) {
-        if (!q.pending) continue;
-        q.pending = false;
-        float prev_pose[6];
-        std::memcpy(prev_pose, q.pose, sizeof(prev_pose));
-        std::memcpy(q.pose, q.pending_pose, sizeof(q.pose));
-        const double dt = q.pending_ts - q.ts;
-        const double inv = 1. / dt;
-        float motion[6];
-        for (int i = 0; i < 6; i++) motion[i] = (float)((q.pose[i] - prev_pose[i]) * inv);
-        const float pv[6] = {0.1f, 0.1f, 0.1f, 0.1f, 0.1f, 0.1f};
-        const float mv[6] = {1, 1, 1, 1, 1, 1};
-        float filtered[6];
-        q.kf.update(q.pose, motion, pv, mv, 0.0, filtered);
-        std::memcpy(q.pose, filtered, sizeof(q.pose));
-        q.ts = q.pending_ts;
-        svo_pose p;
-        std::memcpy(&p, q.pose, sizeof(p));
-        q.trajectory.push_back(p);
-    }
+    if (c->pool) c->pool->parallel_for((int)c->seqs.size(), [c](int s) { flush_one(c->seqs[s]); });
+    else for (Seq& q : c->seqs) flush_one(q);
 }
 
 extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
@@ -443,6 +523,12 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
     for (int i = 0; i < 10; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
     c->seqs.resize(B);
+    if (B >= 16) {
+        // SVO_HOST_THREADS: host threads per ctx for the per-sequence host work (default: up to 8)
+        int nt = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+        if (const char* e = std::getenv("SVO_HOST_THREADS")) nt = std::max(1, std::atoi(e));
+        if (nt > 1) c->pool = new HostPool(nt - 1);
+    }
     for (int s = 0; s < B; s++) {
         Seq& q = c->seqs[s];
         q.d_n = c->d_n_all + 2 * s;
@@ -481,6 +567,12 @@ extern "C" int svo_ctx_destroy(svo_ctx* c) {
     if (!c) return SVO_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (std::getenv("SVO_HOST_TIMING") && c->host_steps > 0) {
+        static const char* names[7] = {"args", "launch", "pose_filter", "wait_frame", "kf_enqueue", "wait_kf", "bookkeeping"};
+        std::fprintf(stderr, "[svo host ms/step over %ld steps]", c->host_steps);
+        for (int i = 0; i < 7; i++) std::fprintf(stderr, " %s=%.3f", names[i], c->host_ms[i] / c->host_steps);
+        std::fprintf(stderr, "\n");
+    }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_args) (void)hipHostFree(c->h_args);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -498,6 +590,7 @@ extern "C" int svo_ctx_destroy(svo_ctx* c) {
         for (ImageSet* s : all) delete s;
     }
     (void)hipStreamDestroy(c->stream);
+    delete c->pool;
     delete c;
     return SVO_OK;
 }
@@ -582,6 +675,12 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     const bool first = c->seqs[0].frame_id < 0;
     int rc;
 #define SVO_MARK(i) do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[i], c->stream)); } while (0)
+    auto hclock = wall0;
+    auto hlap = [&](int i) {
+        const auto now = std::chrono::steady_clock::now();
+        c->host_ms[i] += std::chrono::duration<double, std::milli>(now - hclock).count();
+        hclock = now;
+    };
     SVO_MARK(0);
 
     // ---- images in, pyramids
@@ -614,7 +713,7 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     }
 
     if (!first) {
-        for (int s = 0; s < B; s++) {
+        auto fill = [c](int s) {
             Seq& q = c->seqs[s];
             FrameResult* dr = c->d_res + s;
             // predicted pose = kf.statePre (stereo_slam.cpp:183-192)
@@ -667,8 +766,10 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             fa->kfs = q.d_kfs; fa->kf_id = k.kf_id; fa->kp_index = k.kp_index;
             fa->do_outlier_check = 1; fa->do_update = 1; fa->do_flags = 1; fa->do_reproject = 1;
             fa->width = c->width; fa->height = c->height; fa->inside_count = &dr->inside;
-        }
+        };
+        for (int s = 0; s < B; s++) fill(s);   // ~20 us for 256 sequences: not worth waking the pool
     }
+    hlap(0);   // argument blocks
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
     launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height,
                           mem == SVO_MEM_DEVICE, c->stream);
@@ -707,8 +808,11 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
         SVO_MARK(7);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
+        hlap(1);   // launches
         flush_pending(c);                 // previous frame's pose filter, overlapped with the kernels
+        hlap(2);   // pose filter
         HIP_TRY(hipStreamSynchronize(c->stream));
+        hlap(3);   // wait for the frame
         // KeyFrameManager::keyframe_needed (keyframe_manager.cpp:66-72)
         const int max_keypoints = (c->width / c->cam.grid_width) * (c->height / c->cam.grid_height);
         bool any = false;
@@ -717,10 +821,12 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             any = any || need[s];
         }
         if (any && (rc = enqueue_keyframes(c, need, false))) return rc;
+        hlap(4);   // keyframe enqueue
     }
     HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_n, c->d_n_all, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    hlap(5);   // wait for keyframes + read-back
 
     SVO_MARK(8);
     float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -779,6 +885,8 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
             }
         if (r.overflow) return svo_set_error(SVO_ERR_CAPACITY, "sequence %d: more than %d keypoints", s, c->cap);
     }
+    hlap(6);   // bookkeeping
+    c->host_steps++;
     for (int i = 0; i < 8; i++) c->totals.stage_ms[i] += stage_ms[i];
     c->totals.wall_ms +=
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

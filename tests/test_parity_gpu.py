@@ -75,6 +75,8 @@ def test_ssd_disparity_real_pair_bit_exact(H):
     kps = np.stack([rng.uniform(0, 752, 300), rng.uniform(0, 480, 300)], 1).astype(np.float32)
     _ssd_case(H, left, right, kps, 31, 60, 6, 1)
     _ssd_case(H, left, right, kps, 35, 60, 6, 1)
+    _ssd_case(H, left, right, kps, 33, 64, 8, 1)      # 17 x 65 match map: every block of the MFMA tiling
+    _ssd_case(H, left, right, kps, 5, 3, 1, 0)
 
 
 def test_ssd_disparity_borders_and_ties(H):
