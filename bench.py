@@ -150,14 +150,18 @@ def main():
                                [float(ts[k])] * B) for k in range(n_frames)]
     marks = {}
 
+    # a step queues one frame set per sequence (svo_submit_images); the ctx's sequence groups
+    # work through their queues independently and finish_fn (svo_wait) closes the timed region
     def step_fn(k):
         if k == Wm:
             marks["t0"] = slam.totals()
-        slam.new_images_packed(packed[k])
+        slam.submit_packed(packed[k])
 
     coll_dev = device if (args.backend or "nccl") == "nccl" else None   # gloo: host tensors
-    seconds = multi_seq.timed_steps(step_fn, K, Wm, world, device, coll_dev)
+    seconds = multi_seq.timed_steps(step_fn, K, Wm, world, device, coll_dev, finish_fn=slam.wait)
     t0, t1 = marks["t0"], slam.totals()
+    G = max(int(t1.n_groups), 1)
+    launches = max(int(t1.launches - t0.launches), 1)          # = K * G: one launch of every stage each
     total_frames = B * K * world
     fps = multi_seq.throughput(total_frames, seconds)
     stage_ms = np.array(list(t1.stage_ms)) - np.array(list(t0.stage_ms))
@@ -173,25 +177,26 @@ def main():
         return
     mean_kps = counters["n_kps"] / max(counters["frames"], 1)
     ab = algorithmic_bytes(cfg, mean_kps, mean_kps)
-    per_launch_ms = stage_ms / K
+    per_launch_ms = stage_ms / launches     # HIP events on each group's stream (svo_frame_stats.stage_ms)
+    seqs_per_launch = B / G
     named = {STAGES[i]: float(per_launch_ms[i]) for i in range(8)}
     kernel_stages = ("sparse_align", "klt", "reproj_gn", "ssd_disparity", "filter_update",
                      "images+pyramids")
     dom = max(kernel_stages, key=lambda s: named[s])
-    achieved = ab[dom] * B / (named[dom] * 1e-3) / 1e9 if named[dom] > 0 else 0.0
+    achieved = ab[dom] * seqs_per_launch / (named[dom] * 1e-3) / 1e9 if named[dom] > 0 else 0.0
     # HBM bytes per launch from rocprofv3 PMC passes of this command (tools/pmc_traffic.sh ->
     # profiles/r01_traffic.json); null when that file does not cover this configuration
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("seqs") == B and tj.get("config") == args.config:
+        if tj.get("seqs") == B and tj.get("config") == args.config and tj.get("groups", 1) == G:
             traffic = tj["bytes_per_launch"].get(KERNEL_OF_STAGE[dom])
     except Exception:
         pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": named[dom],
-                "stage_ms_per_step": named,
+                "algorithmic_bytes_per_launch": ab[dom] * seqs_per_launch, "avg_launch_ms": named[dom],
+                "sequences_per_launch": seqs_per_launch, "stage_ms_per_launch": named,
                 "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
 
     single = None
@@ -230,7 +235,8 @@ def main():
                                f"{mean_kps:.0f} patches/frame (synthetic, seeded)",
                    "sequences_per_gpu": B, "frames_per_step": B * world,
                    "keyframes_in_timed_region": counters["keyframes"],
-                   "gn_ms_per_iter": float(stage_ms[2] / max(counters["n_grad"] / B, 1)),
+                   "sequence_groups": G,
+                   "gn_ms_per_iter": float(per_launch_ms[2] / max(counters["n_grad"] / (B * K), 1e-9)),
                    "single_sequence": single, "setup_s": t_setup,
                    "summaries_gathered": int(summaries.shape[0])},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -123,6 +123,17 @@ int svo_ctx_destroy(svo_ctx *ctx);
 int svo_new_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *const *right,
                    int stride, const float *time_stamps, int mem);
 /* n_sequences == 1, host memory: the exact shape of StereoSlam::new_image */
+/* Pipelined form: svo_submit_images() queues one frame set (same arguments; device-resident
+ * images must stay valid until svo_wait) on every sequence group and returns; svo_wait()
+ * blocks until all queued frame sets are processed and reports the first error. The groups
+ * (svo_ctx_get_groups; SVO_GROUPS overrides the default) advance independently, each on its
+ * own HIP stream and host thread, so one group's host round trips (keyframe decision,
+ * argument blocks) overlap the other groups' kernels. svo_new_images = submit + wait; every
+ * getter waits first. */
+int svo_submit_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *const *right,
+                      int stride, const float *time_stamps, int mem);
+int svo_wait(svo_ctx *ctx);
+int svo_ctx_get_groups(svo_ctx *ctx, int *n_groups);
 int svo_new_image(svo_ctx *ctx, const uint8_t *left, int left_stride, const uint8_t *right,
                   int right_stride, int width, int height, float time_stamp);
 
@@ -169,7 +180,11 @@ typedef struct svo_totals {
     int64_t gn_gradient_calls;  /* sum of get_gradient calls of the sparse alignment */
     int64_t gn_cost_calls;
     double  stage_ms[8];        /* sum of svo_frame_stats.stage_ms (timing on)    */
-    double  wall_ms;            /* host wall time spent inside svo_new_images     */
+    double  wall_ms;            /* host wall time spent inside svo_new_images (max over groups) */
+    int64_t launches;           /* frame sets processed, summed over groups: stage_ms / launches =
+                                   mean duration of one stage launch                */
+    int32_t n_groups;           /* independently driven sequence groups of the ctx */
+    int32_t reserved;
 } svo_totals;
 int svo_get_totals(svo_ctx *ctx, svo_totals *out);
 int svo_ctx_enable_timing(svo_ctx *ctx, int on);

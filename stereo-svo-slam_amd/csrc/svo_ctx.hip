@@ -1,4 +1,4 @@
-// svo_ctx.hip — the tracker behind the C ABI: StereoSlam::new_image
+// svo_group.hip — the tracker behind the C ABI: StereoSlam::new_image
 // (src/lib/stereo_slam.cpp:123-271) for B sequences in lock-step.
 //
 // Host side = bookkeeping only: image-set pool, argument blocks, the 12-state
@@ -25,6 +25,9 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <deque>
+#include <memory>
+#include <string>
 #include <cstdlib>
 #include <thread>
 #include <mutex>
@@ -269,7 +272,7 @@ private:
 
 }  // namespace
 
-struct svo_ctx {
+struct svo_group {
     int device, B, width, height, cap, max_kf, n_lk, det_levels, max_cells, merge_cells;
     svo_camera_settings cam;
     hipStream_t stream;
@@ -296,7 +299,7 @@ struct svo_ctx {
 namespace {
 
 template <typename T>
-int dev_alloc(svo_ctx* c, T** p, size_t count) {
+int dev_alloc(svo_group* c, T** p, size_t count) {
     void* q = nullptr;
     HIP_TRY(hipMalloc(&q, sizeof(T) * std::max<size_t>(count, 1)));
     HIP_TRY(hipMemset(q, 0, sizeof(T) * std::max<size_t>(count, 1)));
@@ -307,7 +310,7 @@ int dev_alloc(svo_ctx* c, T** p, size_t count) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int new_image_set(svo_ctx* c, ImageSet** out) {
+int new_image_set(svo_group* c, ImageSet** out) {
     ImageSet* s = new ImageSet();
     size_t off = 0;
     size_t offs_left[SVO_MAX_PYRAMID_LEVELS], offs_lk[SVO_LK_LEVELS], off_right;
@@ -346,7 +349,7 @@ int new_image_set(svo_ctx* c, ImageSet** out) {
     return SVO_OK;
 }
 
-int acquire_set(svo_ctx* c, Seq& q, ImageSet** out) {
+int acquire_set(svo_group* c, Seq& q, ImageSet** out) {
     if (q.free_sets.empty()) {
         ImageSet* s;
         int rc = new_image_set(c, &s);
@@ -364,7 +367,7 @@ void release_set(Seq& q, ImageSet* s) {
     if (--s->refs <= 0) q.free_sets.push_back(s);
 }
 
-int alloc_kps(svo_ctx* c, KpsDev& k, int* n_ptr) {
+int alloc_kps(svo_group* c, KpsDev& k, int* n_ptr) {
     const size_t cap = c->cap;
     int rc;
     if ((rc = dev_alloc(c, &k.kps2d, cap))) return rc;
@@ -384,11 +387,11 @@ int alloc_kps(svo_ctx* c, KpsDev& k, int* n_ptr) {
 }
 
 template <typename T>
-T* args_at(svo_ctx* c, size_t off, int s) { return reinterpret_cast<T*>(c->h_args + off) + s; }
+T* args_at(svo_group* c, size_t off, int s) { return reinterpret_cast<T*>(c->h_args + off) + s; }
 template <typename T>
-T* dargs_at(svo_ctx* c, size_t off, int s = 0) { return reinterpret_cast<T*>(c->d_args + off) + s; }
+T* dargs_at(svo_group* c, size_t off, int s = 0) { return reinterpret_cast<T*>(c->d_args + off) + s; }
 
-int new_keyframe_storage(svo_ctx* c, Seq& q, int s, int id) {
+int new_keyframe_storage(svo_group* c, Seq& q, int s, int id) {
     if (id >= c->max_kf) return svo_set_error(SVO_ERR_CAPACITY, "more than %d keyframes", c->max_kf);
     KfHost k;
     std::memset(&k, 0, sizeof(k));
@@ -440,13 +443,13 @@ static void flush_one(Seq& q) {
     std::memcpy(&p, q.pose, sizeof(p));
     q.trajectory.push_back(p);
 }
-static void flush_pending(svo_ctx* c) {
+static void flush_pending(svo_group* c) {
     if (c->pool) c->pool->parallel_for((int)c->seqs.size(), [c](int s) { flush_one(c->seqs[s]); });
     else for (Seq& q : c->seqs) flush_one(q);
 }
 
-extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
-                              int device, svo_ctx** out) {
+static int grp_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
+                              int device, svo_group** out) {
     if (!cam || !out || width < 16 || height < 16 || n_sequences < 1)
         return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
     if (cam->max_pyramid_levels < 1 || cam->max_pyramid_levels > 7 ||
@@ -464,7 +467,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
         return svo_set_error(SVO_ERR_NO_DEVICE, "no HIP device visible: libsvo_hip has no CPU fallback");
     if (device < 0 || device >= count) return svo_set_error(SVO_ERR_INVALID, "device %d out of range", device);
     HIP_TRY(hipSetDevice(device));
-    svo_ctx* c = new (std::nothrow) svo_ctx();
+    svo_group* c = new (std::nothrow) svo_group();
     if (!c) return svo_set_error(SVO_ERR_INVALID, "out of host memory");
     c->device = device; c->B = n_sequences; c->width = width; c->height = height; c->cam = *cam;
     std::memset(&c->totals, 0, sizeof(c->totals));
@@ -524,8 +527,9 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
 
     c->seqs.resize(B);
     if (B >= 16) {
-        // SVO_HOST_THREADS: host threads per ctx for the per-sequence host work (default: up to 8)
-        int nt = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+        // SVO_HOST_THREADS: host threads per group for the deferred pose filter
+        // (default 1 = off: at the measured kernel times the filter hides behind the GPU work)
+        int nt = 1;
         if (const char* e = std::getenv("SVO_HOST_THREADS")) nt = std::max(1, std::atoi(e));
         if (nt > 1) c->pool = new HostPool(nt - 1);
     }
@@ -563,7 +567,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
     return SVO_OK;
 }
 
-extern "C" int svo_ctx_destroy(svo_ctx* c) {
+static int grp_destroy(svo_group* c) {
     if (!c) return SVO_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -595,13 +599,13 @@ extern "C" int svo_ctx_destroy(svo_ctx* c) {
     return SVO_OK;
 }
 
-extern "C" int svo_ctx_set_exact_pinv(svo_ctx* c, int on) {
+static int grp_set_exact_pinv(svo_group* c, int on) {
     if (!c) return svo_set_error(SVO_ERR_INVALID, "null ctx");
     c->exact_pinv = on != 0;
     return SVO_OK;
 }
 
-extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
+static int grp_enable_timing(svo_group* c, int on) {
     if (!c) return svo_set_error(SVO_ERR_INVALID, "null ctx");
     c->timing = on != 0;
     return SVO_OK;
@@ -609,7 +613,7 @@ extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
 
 // keyframe creation for the sequences flagged in `need`: their argument blocks are
 // packed into the first m slots, so the five launches cover exactly those sequences
-static int enqueue_keyframes(svo_ctx* c, const std::vector<int>& need, bool first_frame) {
+static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool first_frame) {
     const int B = c->B;
     int m = 0;
     for (int s = 0; s < B; s++) {
@@ -664,7 +668,7 @@ static int enqueue_keyframes(svo_ctx* c, const std::vector<int>& need, bool firs
     return SVO_OK;
 }
 
-extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint8_t* const* right,
+static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_t* const* right,
                               int stride, const float* time_stamps, int mem) {
     if (!c || !left || !right || !time_stamps || stride < c->width)
         return svo_set_error(SVO_ERR_INVALID, "svo_new_images: bad arguments");
@@ -887,24 +891,25 @@ extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint
     }
     hlap(6);   // bookkeeping
     c->host_steps++;
+    c->totals.launches++;
     for (int i = 0; i < 8; i++) c->totals.stage_ms[i] += stage_ms[i];
     c->totals.wall_ms +=
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return SVO_OK;
 }
 
-extern "C" int svo_get_totals(svo_ctx* c, svo_totals* out) {
+static int grp_get_totals(svo_group* c, svo_totals* out) {
     if (!c || !out) return svo_set_error(SVO_ERR_INVALID, "svo_get_totals: bad arguments");
     *out = c->totals;
     return SVO_OK;
 }
 
-extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, const uint8_t* right,
+static int grp_new_image(svo_group* c, const uint8_t* left, int left_stride, const uint8_t* right,
                              int right_stride, int width, int height, float time_stamp) {
     if (!c || c->B != 1) return svo_set_error(SVO_ERR_INVALID, "svo_new_image needs a 1-sequence ctx");
     if (width != c->width || height != c->height || left_stride != right_stride)
         return svo_set_error(SVO_ERR_INVALID, "svo_new_image: image size / stride mismatch");
-    return svo_new_images(c, &left, &right, left_stride, &time_stamp, SVO_MEM_HOST);
+    return grp_new_images(c, &left, &right, left_stride, &time_stamp, SVO_MEM_HOST);
 }
 
 #define CHECK_SEQ(c, seq)                                                              \
@@ -914,14 +919,14 @@ extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, c
         HIP_TRY(hipSetDevice((c)->device));                                            \
     } while (0)
 
-extern "C" int svo_get_pose(svo_ctx* c, int seq, float pose[6]) {
+static int grp_get_pose(svo_group* c, int seq, float pose[6]) {
     CHECK_SEQ(c, seq);
     flush_pending(c);
     std::memcpy(pose, c->seqs[seq].pose, sizeof(float) * 6);
     return SVO_OK;
 }
 
-static int fetch_info(svo_ctx* c, int n, const svo_kp2d* d2, const svo_kp3d* d3, const uint32_t* dfl,
+static int fetch_info(svo_group* c, int n, const svo_kp2d* d2, const svo_kp3d* d3, const uint32_t* dfl,
                       const int* dkf, const int* dki, const int* dout, const int* din, const float* dkx,
                       const float* dkP, const float* dsc, const int* dlt, const uint32_t* dcol,
                       svo_kp2d* kps2d, svo_kp3d* kps3d, svo_kp_info* info) {
@@ -957,7 +962,7 @@ static int fetch_info(svo_ctx* c, int n, const svo_kp2d* d2, const svo_kp3d* d3,
     return SVO_OK;
 }
 
-extern "C" int svo_get_frame_keypoints(svo_ctx* c, int seq, svo_kp2d* kps2d, svo_kp3d* kps3d,
+static int grp_get_frame_keypoints(svo_group* c, int seq, svo_kp2d* kps2d, svo_kp3d* kps3d,
                                        svo_kp_info* info, int cap, int* n) {
     CHECK_SEQ(c, seq);
     Seq& q = c->seqs[seq];
@@ -967,13 +972,13 @@ extern "C" int svo_get_frame_keypoints(svo_ctx* c, int seq, svo_kp2d* kps2d, svo
                       k.outl, k.inl, k.kfx, k.kfP, k.score, k.level_type, k.color, kps2d, kps3d, info);
 }
 
-extern "C" int svo_get_keyframe_count(svo_ctx* c, int seq, int* count) {
+static int grp_get_keyframe_count(svo_group* c, int seq, int* count) {
     CHECK_SEQ(c, seq);
     if (count) *count = (int)c->seqs[seq].kfs.size();
     return SVO_OK;
 }
 
-extern "C" int svo_get_keyframe(svo_ctx* c, int seq, int id, svo_kp2d* kps2d, svo_kp3d* kps3d,
+static int grp_get_keyframe(svo_group* c, int seq, int id, svo_kp2d* kps2d, svo_kp3d* kps3d,
                                 svo_kp_info* info, float pose[6], int cap, int* n) {
     CHECK_SEQ(c, seq);
     Seq& q = c->seqs[seq];
@@ -985,7 +990,7 @@ extern "C" int svo_get_keyframe(svo_ctx* c, int seq, int id, svo_kp2d* kps2d, sv
                       nullptr, nullptr, nullptr, nullptr, nullptr, kps2d, kps3d, info);
 }
 
-extern "C" int svo_get_trajectory(svo_ctx* c, int seq, svo_pose* out, int cap, int* n) {
+static int grp_get_trajectory(svo_group* c, int seq, svo_pose* out, int cap, int* n) {
     CHECK_SEQ(c, seq);
     flush_pending(c);
     Seq& q = c->seqs[seq];
@@ -995,7 +1000,7 @@ extern "C" int svo_get_trajectory(svo_ctx* c, int seq, svo_pose* out, int cap, i
     return SVO_OK;
 }
 
-extern "C" int svo_update_pose(svo_ctx* c, int seq, const float pose[6], const float speed[6],
+static int grp_update_pose(svo_group* c, int seq, const float pose[6], const float speed[6],
                                const float pose_var[6], const float speed_var[6], double dt,
                                float filtered[6]) {
     CHECK_SEQ(c, seq);
@@ -1004,8 +1009,270 @@ extern "C" int svo_update_pose(svo_ctx* c, int seq, const float pose[6], const f
     return SVO_OK;
 }
 
-extern "C" int svo_get_frame_stats(svo_ctx* c, int seq, svo_frame_stats* out) {
+static int grp_get_frame_stats(svo_group* c, int seq, svo_frame_stats* out) {
     CHECK_SEQ(c, seq);
     if (out) *out = c->seqs[seq].stats;
     return SVO_OK;
+}
+
+// =====================================================================================
+// svo_ctx: the public object. Its sequences are split over 1..G groups; a group owns a
+// HIP stream, its argument blocks and (G > 1) a host thread that drives it, so the groups
+// run their frames independently: while one group waits for its keyframe decision or fills
+// its argument blocks, the other group's kernels keep the GPU busy, and the latency-bound
+// single-workgroup-per-sequence alignment kernel of one group overlaps the window kernels of
+// the other. svo_submit_images() queues a frame set on every group and returns;
+// svo_wait() drains the queues. svo_new_images() = submit + wait.
+// =====================================================================================
+struct svo_ctx {
+    struct Job {
+        std::vector<const uint8_t*> left, right;
+        std::vector<float> ts;
+        int stride, mem;
+    };
+    struct Worker {
+        svo_group* g = nullptr;
+        int first = 0, count = 0;
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv, cv_idle;
+        std::deque<Job> jobs;
+        bool busy = false, stop = false;
+        int err = SVO_OK;
+        std::string msg;
+    };
+    int B = 0, device = 0;
+    std::vector<std::unique_ptr<Worker>> workers;
+};
+
+namespace {
+
+void worker_run_job(svo_ctx::Worker& w, const svo_ctx::Job& job) {
+    if (w.err != SVO_OK) return;                 // a failed group drops the rest of its queue
+    const int rc = grp_new_images(w.g, job.left.data(), job.right.data(), job.stride, job.ts.data(), job.mem);
+    if (rc != SVO_OK) {
+        w.err = rc;
+        w.msg = svo_last_error();
+    }
+}
+
+void worker_loop(svo_ctx::Worker* w) {
+    for (;;) {
+        svo_ctx::Job job;
+        {
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [w] { return w->stop || !w->jobs.empty(); });
+            if (w->jobs.empty()) return;         // stop requested and nothing left
+            job = std::move(w->jobs.front());
+            w->jobs.pop_front();
+            w->busy = true;
+        }
+        worker_run_job(*w, job);
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->busy = false;
+            if (w->jobs.empty()) w->cv_idle.notify_all();
+        }
+    }
+}
+
+// wait for every group's queue; returns the first stored error (and clears it)
+int ctx_drain(svo_ctx* c) {
+    int rc = SVO_OK;
+    for (auto& wp : c->workers) {
+        svo_ctx::Worker& w = *wp;
+        if (w.th.joinable()) {
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv_idle.wait(lk, [&w] { return w.jobs.empty() && !w.busy; });
+        }
+        if (w.err != SVO_OK && rc == SVO_OK) {
+            rc = svo_set_error(w.err, "%s", w.msg.c_str());
+            w.err = SVO_OK;
+        }
+    }
+    return rc;
+}
+
+svo_ctx::Worker* ctx_locate(svo_ctx* c, int seq, int* local) {
+    for (auto& wp : c->workers)
+        if (seq >= wp->first && seq < wp->first + wp->count) {
+            *local = seq - wp->first;
+            return wp.get();
+        }
+    return nullptr;
+}
+
+}  // namespace
+
+#define CTX_SEQ(c, seq, w, local)                                                     \
+    int local = 0;                                                                     \
+    svo_ctx::Worker* w = nullptr;                                                      \
+    do {                                                                               \
+        if (!(c) || (seq) < 0 || (seq) >= (c)->B)                                      \
+            return svo_set_error(SVO_ERR_INVALID, "bad ctx / sequence index");         \
+        int rc_ = ctx_drain(c);                                                        \
+        if (rc_) return rc_;                                                           \
+        w = ctx_locate(c, seq, &local);                                                \
+    } while (0)
+
+extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
+                              int device, svo_ctx** out) {
+    if (!cam || !out || n_sequences < 1) return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
+    // SVO_GROUPS: number of independently driven groups (default 2 from 64 sequences on: measured
+    // +12 % at 64 and +20 % at 256 sequences on MI355X; more groups starve the alignment kernel)
+    int G = n_sequences >= 64 ? 2 : 1;
+    if (const char* e = std::getenv("SVO_GROUPS")) G = std::atoi(e);
+    G = std::max(1, std::min(G, std::min(n_sequences, 16)));
+    svo_ctx* c = new (std::nothrow) svo_ctx();
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "out of host memory");
+    c->B = n_sequences; c->device = device;
+    int first = 0;
+    for (int g = 0; g < G; g++) {
+        const int count = n_sequences / G + (g < n_sequences % G ? 1 : 0);
+        auto w = std::make_unique<svo_ctx::Worker>();
+        w->first = first; w->count = count;
+        const int rc = grp_create(cam, width, height, count, device, &w->g);
+        if (rc) {
+            for (auto& o : c->workers) grp_destroy(o->g);
+            delete c;
+            return rc;
+        }
+        first += count;
+        c->workers.push_back(std::move(w));
+    }
+    if (G > 1)
+        for (auto& w : c->workers) w->th = std::thread(worker_loop, w.get());
+    *out = c;
+    return SVO_OK;
+}
+
+extern "C" int svo_ctx_destroy(svo_ctx* c) {
+    if (!c) return SVO_OK;
+    (void)ctx_drain(c);
+    for (auto& w : c->workers) {
+        if (w->th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(w->m);
+                w->stop = true;
+            }
+            w->cv.notify_all();
+            w->th.join();
+        }
+        grp_destroy(w->g);
+    }
+    delete c;
+    return SVO_OK;
+}
+
+extern "C" int svo_ctx_get_groups(svo_ctx* c, int* n_groups) {
+    if (!c || !n_groups) return svo_set_error(SVO_ERR_INVALID, "svo_ctx_get_groups: bad arguments");
+    *n_groups = (int)c->workers.size();
+    return SVO_OK;
+}
+
+extern "C" int svo_submit_images(svo_ctx* c, const uint8_t* const* left, const uint8_t* const* right,
+                                 int stride, const float* time_stamps, int mem) {
+    if (!c || !left || !right || !time_stamps) return svo_set_error(SVO_ERR_INVALID, "svo_submit_images: bad arguments");
+    for (auto& wp : c->workers) {
+        svo_ctx::Worker& w = *wp;
+        svo_ctx::Job job;
+        job.left.assign(left + w.first, left + w.first + w.count);
+        job.right.assign(right + w.first, right + w.first + w.count);
+        job.ts.assign(time_stamps + w.first, time_stamps + w.first + w.count);
+        job.stride = stride; job.mem = mem;
+        if (w.th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(w.m);
+                w.jobs.push_back(std::move(job));
+            }
+            w.cv.notify_one();
+        } else {
+            worker_run_job(w, job);              // single group: runs on the caller's thread
+        }
+    }
+    return SVO_OK;
+}
+
+extern "C" int svo_wait(svo_ctx* c) {
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "svo_wait: bad ctx");
+    return ctx_drain(c);
+}
+
+extern "C" int svo_new_images(svo_ctx* c, const uint8_t* const* left, const uint8_t* const* right,
+                              int stride, const float* time_stamps, int mem) {
+    const int rc = svo_submit_images(c, left, right, stride, time_stamps, mem);
+    return rc ? rc : svo_wait(c);
+}
+
+extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, const uint8_t* right,
+                             int right_stride, int width, int height, float time_stamp) {
+    if (!c || c->B != 1) return svo_set_error(SVO_ERR_INVALID, "svo_new_image needs a 1-sequence ctx");
+    return grp_new_image(c->workers[0]->g, left, left_stride, right, right_stride, width, height, time_stamp);
+}
+
+extern "C" int svo_ctx_set_exact_pinv(svo_ctx* c, int on) {
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "bad ctx");
+    int rc = ctx_drain(c);
+    for (auto& w : c->workers)
+        if (!rc) rc = grp_set_exact_pinv(w->g, on);
+    return rc;
+}
+
+extern "C" int svo_ctx_enable_timing(svo_ctx* c, int on) {
+    if (!c) return svo_set_error(SVO_ERR_INVALID, "bad ctx");
+    int rc = ctx_drain(c);
+    for (auto& w : c->workers)
+        if (!rc) rc = grp_enable_timing(w->g, on);
+    return rc;
+}
+
+extern "C" int svo_get_totals(svo_ctx* c, svo_totals* out) {
+    if (!c || !out) return svo_set_error(SVO_ERR_INVALID, "svo_get_totals: bad arguments");
+    int rc = ctx_drain(c);
+    if (rc) return rc;
+    std::memset(out, 0, sizeof(*out));
+    for (auto& w : c->workers) {
+        svo_totals t;
+        if ((rc = grp_get_totals(w->g, &t))) return rc;
+        out->frames += t.frames; out->keyframes += t.keyframes; out->keypoints += t.keypoints;
+        out->gn_gradient_calls += t.gn_gradient_calls; out->gn_cost_calls += t.gn_cost_calls;
+        for (int i = 0; i < 8; i++) out->stage_ms[i] += t.stage_ms[i];
+        out->wall_ms = std::max(out->wall_ms, t.wall_ms);
+        out->launches += t.launches;
+    }
+    out->n_groups = (int)c->workers.size();
+    return SVO_OK;
+}
+
+extern "C" int svo_get_pose(svo_ctx* c, int seq, float pose[6]) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_pose(w->g, local, pose);
+}
+extern "C" int svo_get_frame_keypoints(svo_ctx* c, int seq, svo_kp2d* kps2d, svo_kp3d* kps3d,
+                                       svo_kp_info* info, int cap, int* n) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_frame_keypoints(w->g, local, kps2d, kps3d, info, cap, n);
+}
+extern "C" int svo_get_keyframe_count(svo_ctx* c, int seq, int* count) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_keyframe_count(w->g, local, count);
+}
+extern "C" int svo_get_keyframe(svo_ctx* c, int seq, int id, svo_kp2d* kps2d, svo_kp3d* kps3d,
+                                svo_kp_info* info, float pose[6], int cap, int* n) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_keyframe(w->g, local, id, kps2d, kps3d, info, pose, cap, n);
+}
+extern "C" int svo_get_trajectory(svo_ctx* c, int seq, svo_pose* out, int cap, int* n) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_trajectory(w->g, local, out, cap, n);
+}
+extern "C" int svo_update_pose(svo_ctx* c, int seq, const float pose[6], const float speed[6],
+                               const float pose_var[6], const float speed_var[6], double dt,
+                               float filtered[6]) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_update_pose(w->g, local, pose, speed, pose_var, speed_var, dt, filtered);
+}
+extern "C" int svo_get_frame_stats(svo_ctx* c, int seq, svo_frame_stats* out) {
+    CTX_SEQ(c, seq, w, local);
+    return grp_get_frame_stats(w->g, local, out);
 }

@@ -20,7 +20,8 @@ SYMBOLS = (
     "svo_handle_set_stream", "svo_handle_synchronize", "svo_build_pyramid",
     "svo_build_lk_pyramid", "svo_sparse_align", "svo_klt_track", "svo_reproj_gn",
     "svo_ssd_disparity", "svo_depth_filter_update",
-    "svo_ctx_create", "svo_ctx_destroy", "svo_new_images", "svo_new_image", "svo_get_pose",
+    "svo_ctx_create", "svo_ctx_destroy", "svo_new_images", "svo_submit_images", "svo_wait",
+    "svo_ctx_get_groups", "svo_new_image", "svo_get_pose",
     "svo_get_frame_keypoints", "svo_get_keyframe_count", "svo_get_keyframe",
     "svo_get_trajectory", "svo_update_pose", "svo_get_frame_stats", "svo_ctx_enable_timing",
     "svo_get_totals", "svo_handle_set_exact_pinv", "svo_ctx_set_exact_pinv",

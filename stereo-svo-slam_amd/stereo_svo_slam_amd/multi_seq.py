@@ -57,21 +57,26 @@ def _barrier(world, device):
             dist.barrier()
 
 
-def timed_steps(step_fn, steps, warmup, world, device=None, coll_device="same"):
+def timed_steps(step_fn, steps, warmup, world, device=None, coll_device="same", finish_fn=None):
     """Driver contract: `warmup` untimed steps, then exactly `steps` steps bracketed
     by barrier + device synchronize on both sides; returns MAX-over-ranks seconds.
     `device` is synchronized; collectives run on `coll_device` (default: the same;
-    None = host tensors, e.g. gloo)."""
+    None = host tensors, e.g. gloo). `finish_fn` drains work that step_fn only queued
+    (svo_submit_images): it runs inside the timed region, before the closing synchronize."""
     if coll_device == "same":
         coll_device = device
     for k in range(warmup):
         step_fn(k)
+    if finish_fn:
+        finish_fn()
     _sync(device)
     _barrier(world, coll_device)
     _sync(device)
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
         step_fn(k)
+    if finish_fn:
+        finish_fn()
     _sync(device)
     t1 = time.perf_counter()
     _barrier(world, coll_device)

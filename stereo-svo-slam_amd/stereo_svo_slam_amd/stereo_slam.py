@@ -44,7 +44,8 @@ class Totals(C.Structure):
     """svo_totals (include/svo_hip.h)."""
     _fields_ = [("frames", C.c_int64), ("keyframes", C.c_int64), ("keypoints", C.c_int64),
                 ("gn_gradient_calls", C.c_int64), ("gn_cost_calls", C.c_int64),
-                ("stage_ms", C.c_double * 8), ("wall_ms", C.c_double)]
+                ("stage_ms", C.c_double * 8), ("wall_ms", C.c_double),
+                ("launches", C.c_int64), ("n_groups", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Frame:
@@ -129,6 +130,19 @@ class StereoSlamBatch:
 
     def new_images_packed(self, packed):
         _check(lib().svo_new_images(self._ctx, packed[0], packed[1], packed[2], packed[3], 1))
+
+    def submit_packed(self, packed):
+        """Pipelined form (svo_submit_images): queues the frame set on every sequence group and
+        returns; `packed` (and its device images) must stay alive until wait()."""
+        _check(lib().svo_submit_images(self._ctx, packed[0], packed[1], packed[2], packed[3], 1))
+
+    def wait(self):
+        _check(lib().svo_wait(self._ctx))
+
+    def groups(self):
+        n = C.c_int(0)
+        _check(lib().svo_ctx_get_groups(self._ctx, C.byref(n)))
+        return n.value
 
     def totals(self):
         t = Totals()

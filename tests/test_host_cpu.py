@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     assert stereo_slam.KP_INFO_DTYPE.itemsize == 44
     assert C.sizeof(stereo_slam.GnTrace) == 52
     assert C.sizeof(stereo_slam.FrameStats) == 6 * 4 + 12 * 4 + 3 * 4 + 8 * 4 + 9 * 52
-    assert C.sizeof(stereo_slam.Totals) == 5 * 8 + 8 * 8 + 8
+    assert C.sizeof(stereo_slam.Totals) == 5 * 8 + 8 * 8 + 8 + 8 + 4 + 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

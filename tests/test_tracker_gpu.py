@@ -130,6 +130,40 @@ def test_batch_equals_single():
             assert np.array_equal(a.info, b.info)
 
 
+def test_groups_and_pipelined_submit_equal_lockstep(monkeypatch):
+    """Sequence groups (own stream + host thread each) and svo_submit_images / svo_wait give
+    the results of the single-group, call-per-frame form: 5 sequences as 1 group vs 2 groups
+    (3 + 2 sequences), the latter with all frames queued before one wait."""
+    import torch
+    n_frames = 7
+    seqs = [synth.make_sequence("tiny", n_frames, s, device="cpu") for s in range(5)]
+    cfg = seqs[0][0]
+    monkeypatch.setenv("SVO_GROUPS", "1")
+    one = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 5)
+    monkeypatch.setenv("SVO_GROUPS", "2")
+    two = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 5)
+    assert one.groups() == 1 and two.groups() == 2
+    dev_l = [[s[1][k].cuda() for s in seqs] for k in range(n_frames)]
+    dev_r = [[s[2][k].cuda() for s in seqs] for k in range(n_frames)]
+    torch.cuda.synchronize()
+    packs = [two.pack_images(dev_l[k], dev_r[k], [float(s[4][k]) for s in seqs]) for k in range(n_frames)]
+    for k in range(n_frames):
+        one.new_images([s[1][k].numpy() for s in seqs], [s[2][k].numpy() for s in seqs],
+                       [float(s[4][k]) for s in seqs])
+        two.submit_packed(packs[k])
+    two.wait()
+    t1, t2 = one.totals(), two.totals()
+    assert (t1.frames, t1.keyframes, t1.keypoints) == (t2.frames, t2.keyframes, t2.keypoints)
+    assert t2.n_groups == 2 and t2.launches == 2 * n_frames and t1.launches == n_frames
+    for i in range(5):
+        a, b = one.get_frame(i), two.get_frame(i)
+        assert np.array_equal(a.pose, b.pose)
+        assert np.array_equal(a.kps2d, b.kps2d) and np.array_equal(a.kps3d, b.kps3d)
+        assert np.array_equal(a.info, b.info)
+        assert np.array_equal(one.get_trajectory(i), two.get_trajectory(i))
+        assert one.num_keyframes(i) == two.num_keyframes(i)
+
+
 def test_update_pose_matches_oracle():
     cfg = dict(synth.CONFIGS["tiny"])
     gpu = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1)

@@ -14,7 +14,7 @@ for spec in sys.argv[1:]:
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        st = d["roofline"]["stage_ms_per_step"]
+        st = d["roofline"]["stage_ms_per_launch"]
         print(f"{name:14s} fps {d['value']:9.0f} step {d['ms_per_step']:.3f} ms | " + " ".join(f"{k[:6]}={v:.3f}" for k, v in st.items()), flush=True)
     except Exception as e:
         print(name, "FAILED", e, r.stderr[-500:])
