@@ -198,12 +198,18 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     float nx, ny;
     if (a.proj_pose) {
         // frame.kps.kps2d = project_keypoints(estimated_pose, kps3d)   (stereo_slam.cpp:73-80)
-        float pose[6];
-        for (int i = 0; i < 6; i++) pose[i] = a.proj_pose[i];
-        PoseMats pm;
-        pose_mats(pose, pm);
         const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
-        const svo_kp2d q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+        svo_kp2d q;
+        if (a.proj_mats) {
+            const PoseMats& pm = *a.proj_mats;
+            q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+        } else {
+            float pose[6];
+            for (int i = 0; i < 6; i++) pose[i] = a.proj_pose[i];
+            PoseMats pm;
+            pose_mats(pose, pm);
+            q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+        }
         nx = q.x; ny = q.y;
         ref = kf.kps2d[a.kp_index[kp]];
         if (tid == 0) {

@@ -521,6 +521,11 @@ __device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, co
     if (tid == 0) {
         for (int j = 0; j < 6; j++) a.pose_out[j] = est[j];
         if (a.cost_out) *a.cost_out = last_cost;
+        if (a.mats_out) {    // once per sequence instead of once per keypoint workgroup of klt_track_kernel
+            PoseMats pm;
+            pose_mats(est, pm);
+            *a.mats_out = pm;
+        }
     }
 }
 

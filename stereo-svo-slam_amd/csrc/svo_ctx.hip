@@ -179,6 +179,7 @@ struct Seq {
     float* disparity = nullptr;
     float4* sia_cache = nullptr;
     float* sia_kpws = nullptr;
+    PoseMats* sia_mats = nullptr;    // rotation matrices of the aligned pose (sia_gn_kernel -> klt_track_kernel)
     KfDev* d_kfs = nullptr;
     std::vector<KfHost> kfs;
     DetCell* det = nullptr; int* n_det = nullptr;
@@ -544,6 +545,7 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
         if ((rc = dev_alloc(c, &q.disparity, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.sia_cache, (size_t)c->cap * 16))) return rc;
         if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)(c->cap + 16) * 40))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_mats, 1))) return rc;
         if ((rc = dev_alloc(c, &q.d_kfs, (size_t)c->max_kf))) return rc;
         if ((rc = dev_alloc(c, &q.det, (size_t)SVO_MAX_PYRAMID_LEVELS * c->max_cells))) return rc;
         if ((rc = dev_alloc(c, &q.n_det, (size_t)SVO_MAX_PYRAMID_LEVELS))) return rc;
@@ -740,6 +742,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
             sa->cam = c->cam; sa->n_ptr = k.n; sa->kps2d = k.kps2d; sa->kps3d = k.kps3d; sa->flags = k.flags;
             sa->pose_guess = d_guess; sa->pose_out = dr->pose_sia; sa->cost_out = &dr->sia_cost;
             sa->trace = dr->sia_trace; sa->cache = q.sia_cache; sa->kp_ws = q.sia_kpws;
+            sa->mats_out = q.sia_mats;
             sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap; sa->exact_pinv = c->exact_pinv;
             KltArgs* ka = args_at<KltArgs>(c, c->off_klt, s);
             std::memset(ka, 0, sizeof(*ka));
@@ -747,7 +750,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
             for (int l = 0; l < c->n_lk; l++) ka->cur[l] = q.cur_set->lk[l];
             ka->n_ptr = k.n; ka->prev_pts = nullptr; ka->cur_pts = q.tracked; ka->status = q.klt_status;
             ka->err = q.klt_err; ka->win = c->cam.window_size_opt_flow;
-            ka->proj_pose = dr->pose_sia; ka->kps3d = k.kps3d; ka->proj_out = k.kps2d;
+            ka->proj_pose = dr->pose_sia; ka->proj_mats = q.sia_mats; ka->kps3d = k.kps3d; ka->proj_out = k.kps2d;
             ka->kp_index = k.kp_index; ka->ref_out = nullptr; ka->cam = c->cam;
             ReprojArgs* ra = args_at<ReprojArgs>(c, c->off_rp, s);
             std::memset(ra, 0, sizeof(*ra));

@@ -43,6 +43,7 @@ struct SiaArgs {
     int dbg_level;
     int cap;
     int exact_pinv;               // 1: always the reference's SVD pseudo-inverse (slow, parity mode)
+    PoseMats* mats_out;           // optional: rotation matrices of pose_out, for the kernels that project with it
 };
 void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int cap, hipStream_t stream);
@@ -74,6 +75,7 @@ struct KltArgs {
     int win;
     // optional fused projection (tracker path): cur_pts = project(pose, kps3d) first
     const float* proj_pose;       // [6] or null
+    const PoseMats* proj_mats;    // optional: pose_mats(proj_pose) computed once per sequence (sia_gn_kernel)
     const svo_kp3d* kps3d;
     svo_kp2d* proj_out;           // [n] projected positions (frame.kps.kps2d before the merge)
     const int* kp_index;          // [n] with proj_pose: prev_pts is gathered from kfs[kf_id].kps2d[kp_index]

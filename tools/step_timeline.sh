@@ -28,5 +28,21 @@ with open(out, "w") as f:
     for s, e, n in ev[start:]:
         f.write(f"{(s - t0) / 1e3:10.1f} us  dur {(e - s) / 1e3:8.1f}  gap {(s - prev_end) / 1e3:8.1f}  {n}\n")
         prev_end = max(prev_end, e)
-print(open(out).read())
+# utilisation over the listed window: union of busy intervals vs span, and per-kernel sums
+span0, span1 = ev[start][0], max(e for _, e, _ in ev[start:])
+busy, cur_s, cur_e = 0, None, None
+for s_, e_, _ in ev[start:]:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+busy += cur_e - cur_s
+import collections
+per = collections.defaultdict(float)
+for s_, e_, n_ in ev[start:]: per[n_] += (e_ - s_) / 1e3
+with open(out, "a") as f:
+    f.write(f"\nspan {(span1 - span0) / 1e3:.1f} us, some kernel or copy running {busy / 1e3:.1f} us ({100.0 * busy / (span1 - span0):.1f} %)\n")
+    for n_, t_ in sorted(per.items(), key=lambda kv: -kv[1]): f.write(f"  {t_:10.1f} us  {n_}\n")
+print(open(out).read()[-3000:])
 PY
