@@ -121,38 +121,79 @@ __global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __re
 
 // ------------------------------------------------------------------ P2
 constexpr int PD_TW = 64, PD_TH = 16;                 // output tile
-constexpr int PD_IW = 2 * PD_TW + 3, PD_IH = 2 * PD_TH + 3;  // input tile with halo
+constexpr int PD_IH = 2 * PD_TH + 3;                  // input rows with halo
+constexpr int PD_IWB = 2 * PD_TW + 8;                 // input bytes per row: columns 2*ox0-4 .. 2*ox0+131 (dword aligned)
+constexpr int PD_IWD = PD_IWB / 4;                    // 34 dwords
 
+// cv::pyrDown: separable [1 4 6 4 1] / 16 per axis, BORDER_REFLECT_101, (v + 128) >> 8.
+// The input tile is staged with dword loads (byte loads + reflection only for the dwords that
+// cross the left / right image border); the horizontal pass is one v_dot4 with (1,4,6,4) plus one byte per output,
+// the vertical pass works on two 16-bit columns packed in a dword (row sums <= 4080, column
+// sums <= 65280 < 2^16, so the halves never carry into each other).
 __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrArgs* __restrict__ args, int src_level) {
     const PyrArgs& a = args[blockIdx.z];
     const ImgView src = a.level[src_level];
     const ImgView dst = a.level[src_level + 1];
-    __shared__ uint8_t in[PD_IH][PD_IW + 1];
-    __shared__ uint16_t hrow[PD_IH][PD_TW];
+    __shared__ __attribute__((aligned(16))) uint32_t in[PD_IH][PD_IWD];
+    __shared__ __attribute__((aligned(16))) uint32_t hrow[PD_IH][PD_TW / 2];    // 2 x u16 per dword
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
     if (ox0 >= dst.w || oy0 >= dst.h) return;
+    const int ix0 = 2 * ox0 - 4, iy0 = 2 * oy0 - 2;
 
-    for (int i = tid; i < PD_IH * PD_IW; i += 256) {
-        const int r = i / PD_IW, c = i % PD_IW;
-        const int sy = reflect101(2 * oy0 - 2 + r, src.h);
-        const int sx = reflect101(2 * ox0 - 2 + c, src.w);
-        in[r][c] = src.data[(size_t)sy * src.stride + sx];
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src.data) | (uintptr_t)src.stride) & 3) == 0;
+    for (int i = tid; i < PD_IH * PD_IWD; i += 256) {
+        const int r = i / PD_IWD, d = i - r * PD_IWD;
+        const uint8_t* row = src.data + (size_t)reflect101(iy0 + r, src.h) * src.stride;
+        const int x = ix0 + 4 * d;
+        uint32_t v;
+        if (aligned && x >= 0 && x + 4 <= src.w) {
+            v = *reinterpret_cast<const uint32_t*>(row + x);
+        } else {                                   // dwords on the left / right image border
+            v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x + b, src.w)] << (8 * b);
+        }
+        in[r][d] = v;
     }
     __syncthreads();
-    for (int i = tid; i < PD_IH * PD_TW; i += 256) {
-        const int r = i / PD_TW, c = i % PD_TW;
-        const uint8_t* p = &in[r][2 * c];
-        hrow[r][c] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
+    // horizontal: 4 outputs c0..c0+3 per item from tile bytes 2*c0+2 .. 2*c0+12 (4 dwords)
+    for (int i = tid; i < PD_IH * (PD_TW / 4); i += 256) {
+        const int r = i / (PD_TW / 4), q = i - r * (PD_TW / 4);
+        const uint32_t* w = &in[r][2 * q];
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const uint32_t K = 0x04060401u;                                  // taps 1 4 6 4 (then + the 5th byte)
+        const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K, (w1 >> 16) & 255u, false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(w1, K, w2 & 255u, false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K, (w2 >> 16) & 255u, false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(w2, K, w3 & 255u, false);
+        hrow[r][2 * q] = h0 | (h1 << 16);
+        hrow[r][2 * q + 1] = h2 | (h3 << 16);
     }
     __syncthreads();
-    for (int i = tid; i < PD_TH * PD_TW; i += 256) {
-        const int r = i / PD_TW, c = i % PD_TW;
-        const int v = hrow[2 * r + 2][c] * 6 + (hrow[2 * r + 1][c] + hrow[2 * r + 3][c]) * 4 +
-                      hrow[2 * r][c] + hrow[2 * r + 4][c];
-        const int gy = oy0 + r, gx = ox0 + c;
-        if (gy < dst.h && gx < dst.w)
-            const_cast<uint8_t*>(dst.data)[(size_t)gy * dst.stride + gx] = (uint8_t)((v + 128) >> 8);
+    // vertical: 4 outputs per item (two packed dwords), stored as one dword
+    for (int i = tid; i < PD_TH * (PD_TW / 4); i += 256) {
+        const int r = i / (PD_TW / 4), q = i - r * (PD_TW / 4);
+        uint32_t o[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = 2 * q + k;
+            const uint32_t v = hrow[2 * r][c] + hrow[2 * r + 4][c] + 4u * (hrow[2 * r + 1][c] + hrow[2 * r + 3][c]) +
+                               6u * hrow[2 * r + 2][c] + 0x00800080u;
+            o[k] = ((v >> 8) & 255u) | ((v >> 24) << 8);              // two result bytes
+        }
+        const uint32_t out4 = o[0] | (o[1] << 16);
+        const int gy = oy0 + r, gx = ox0 + 4 * q;
+        if (gy < dst.h && gx < dst.w) {
+            uint8_t* p = const_cast<uint8_t*>(dst.data) + (size_t)gy * dst.stride + gx;
+            if (gx + 4 <= dst.w && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+                *reinterpret_cast<uint32_t*>(p) = out4;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (gx + b < dst.w) p[b] = (uint8_t)(out4 >> (8 * b));
+            }
+        }
     }
 }
 

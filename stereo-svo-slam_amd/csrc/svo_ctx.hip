@@ -285,6 +285,10 @@ struct svo_group {
     FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;
     int* h_n = nullptr;          // pinned [B*2]
     int* d_n_all = nullptr;      // [B*2]
+    // d_res | d_n_all | d_inside are one device block mirrored by one pinned block: the end-of-frame
+    // read-back is a single copy, the keyframe decision reads back only the B inside-counters
+    int* d_inside = nullptr; int* h_inside = nullptr;
+    size_t readback_bytes = 0;
     size_t sia_lds = 0;
     bool timing = false;
     int exact_pinv = 0;
@@ -520,10 +524,18 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     std::memset(c->h_args, 0, off);
     int rc;
     if ((rc = dev_alloc(c, &c->d_args, off))) return rc;
-    if ((rc = dev_alloc(c, &c->d_res, (size_t)B))) return rc;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_res), sizeof(FrameResult) * B, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_n), sizeof(int) * 2 * B, hipHostMallocDefault));
-    if ((rc = dev_alloc(c, &c->d_n_all, (size_t)2 * B))) return rc;
+    {
+        const size_t res_bytes = sizeof(FrameResult) * B, n_bytes = sizeof(int) * 2 * B, in_bytes = sizeof(int) * B;
+        c->readback_bytes = res_bytes + n_bytes;
+        uint8_t* hb = nullptr; uint8_t* db = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hb), res_bytes + n_bytes + in_bytes, hipHostMallocDefault));
+        std::memset(hb, 0, res_bytes + n_bytes + in_bytes);
+        if ((rc = dev_alloc(c, &db, res_bytes + n_bytes + in_bytes))) return rc;
+        c->h_res = reinterpret_cast<FrameResult*>(hb); c->d_res = reinterpret_cast<FrameResult*>(db);
+        c->h_n = reinterpret_cast<int*>(hb + res_bytes); c->d_n_all = reinterpret_cast<int*>(db + res_bytes);
+        c->h_inside = reinterpret_cast<int*>(hb + res_bytes + n_bytes);
+        c->d_inside = reinterpret_cast<int*>(db + res_bytes + n_bytes);
+    }
     for (int i = 0; i < 10; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
     c->seqs.resize(B);
@@ -581,8 +593,7 @@ static int grp_destroy(svo_group* c) {
     }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_args) (void)hipHostFree(c->h_args);
-    if (c->h_res) (void)hipHostFree(c->h_res);
-    if (c->h_n) (void)hipHostFree(c->h_n);
+    if (c->h_res) (void)hipHostFree(c->h_res);   // one pinned block: results, counts, inside counters
     for (int i = 0; i < 10; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     // ImageSet structs: owned by the free lists, the current/previous pointers and keyframes
@@ -772,7 +783,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
             fa->kf_variance = k.kfP; fa->disparity = q.disparity;
             fa->kfs = q.d_kfs; fa->kf_id = k.kf_id; fa->kp_index = k.kp_index;
             fa->do_outlier_check = 1; fa->do_update = 1; fa->do_flags = 1; fa->do_reproject = 1;
-            fa->width = c->width; fa->height = c->height; fa->inside_count = &dr->inside;
+            fa->width = c->width; fa->height = c->height; fa->inside_count = c->d_inside + s;
         };
         for (int s = 0; s < B; s++) fill(s);   // ~20 us for 256 sequences: not worth waking the pool
     }
@@ -814,7 +825,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         launch_filter(dargs_at<FilterArgs>(c, c->off_filt), B, c->stream);
         SVO_MARK(7);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_inside, c->d_inside, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
         hlap(1);   // launches
         flush_pending(c);                 // previous frame's pose filter, overlapped with the kernels
         hlap(2);   // pose filter
@@ -824,14 +835,13 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         const int max_keypoints = (c->width / c->cam.grid_width) * (c->height / c->cam.grid_height);
         bool any = false;
         for (int s = 0; s < B; s++) {
-            need[s] = (double)c->h_res[s].inside < 0.66 * max_keypoints ? 1 : 0;
+            need[s] = (double)c->h_inside[s] < 0.66 * max_keypoints ? 1 : 0;
             any = any || need[s];
         }
         if (any && (rc = enqueue_keyframes(c, need, false))) return rc;
         hlap(4);   // keyframe enqueue
     }
-    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, sizeof(FrameResult) * B, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_n, c->d_n_all, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, c->readback_bytes, hipMemcpyDeviceToHost, c->stream));   // results + counts
     HIP_TRY(hipStreamSynchronize(c->stream));
     hlap(5);   // wait for keyframes + read-back
 
@@ -875,7 +885,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         svo_frame_stats& st = q.stats;
         std::memset(&st, 0, sizeof(st));
         st.frame_id = q.frame_id; st.is_keyframe = need[s]; st.n_keypoints = q.n_host;
-        st.n_keyframes = (int)q.kfs.size(); st.inside_count = r.inside; st.overflow = r.overflow;
+        st.n_keyframes = (int)q.kfs.size(); st.inside_count = first ? 0 : c->h_inside[s]; st.overflow = r.overflow;
         std::memcpy(st.pose_sia, r.pose_sia, sizeof(st.pose_sia));
         std::memcpy(st.pose_refined, r.pose_refined, sizeof(st.pose_refined));
         st.sia_cost = r.sia_cost; st.reproj_cost = r.reproj_cost; st.sia_ms = sia_ms;
