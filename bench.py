@@ -116,8 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--seqs", type=int, default=512,
-                    help="sequences per GPU (two groups of 256 = one alignment workgroup per CU each)")
+    ap.add_argument("--seqs", type=int, default=768,
+                    help="sequences per GPU (default: three groups of 256 = one alignment workgroup per CU each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm", type=float, default=1.5,
                     help="seconds of untimed load on a throw-away ctx before the warm-up steps (clock ramp)")

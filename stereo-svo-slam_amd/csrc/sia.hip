@@ -22,6 +22,8 @@
 //     its Hessian: the member is shadowed, pose_estimator.cpp:399 vs :61),
 //     reduced over the workgroup and solved on lane 0.
 #include "svo_kernels.hpp"
+#include <atomic>
+#include <algorithm>
 #include "svo_reduce.hpp"
 
 namespace svo {
@@ -98,7 +100,8 @@ __device__ inline float patch_sum_img(const LevelImg<LDS>& im, float cx, float c
 // per-keypoint arrays are in LDS; false: they stay in HBM (large configurations).
 template <bool LDS>
 struct LevelCtx {
-    LevelImg<LDS> cur, prev;
+    LevelImg<LDS> cur;      // sampled by every iteration: LDS copy when the working set is in LDS
+    LevelImg<false> prev;   // read once per level (reference patches): stays in HBM / L2
     float fx, fy, cx, cy;
     int patch;              // window_size_pose_estimator
     // per patch pixel (n*16): reference cost sample, gradients, reference patch sum
@@ -325,7 +328,7 @@ __device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, Si
 // It lives in LDS when it fits the budget (n <= ~250 at 752x480), else in the
 // HBM workspace (SiaArgs::kp_ws / cache). Host and device share this function.
 struct SiaLds {
-    size_t proj, kp_cw, kp_cb, kp_J, kp_rows, kp_pt, kp_G, img_cur, img_prev, rec, total;
+    size_t proj, kp_cw, kp_cb, kp_J, kp_rows, kp_pt, kp_G, img_cur, rec, total;
     int img_bytes;
 };
 
@@ -343,7 +346,6 @@ __host__ __device__ inline SiaLds sia_lds_layout(int n, int max_img_bytes) {
     const size_t img = ((size_t)max_img_bytes + 15) & ~(size_t)15;
     l.img_bytes = (int)img;
     l.img_cur = off; off += img;
-    l.img_prev = off; off += img;
     l.rec = off;     off += np * 256;
     l.total = off;
     return l;
@@ -392,21 +394,15 @@ __device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, co
         __syncthreads();                 // everybody is done with the previous level's LDS
         if (LDS) {
             uint8_t* sc = dyn + lay.img_cur;
-            uint8_t* sp = dyn + lay.img_prev;
             for (int i = tid; i < cur.w * cur.h; i += SIA_THREADS) {
                 const int r = i / cur.w, c = i - r * cur.w;
                 mem_st<true>(sc, i, cur.data[(size_t)r * cur.stride + c]);
             }
-            for (int i = tid; i < prev.w * prev.h; i += SIA_THREADS) {
-                const int r = i / prev.w, c = i - r * prev.w;
-                mem_st<true>(sp, i, prev.data[(size_t)r * prev.stride + c]);
-            }
             L.cur = LevelImg<LDS>{sc, cur.w, cur.h, cur.w};
-            L.prev = LevelImg<LDS>{sp, prev.w, prev.h, prev.w};
         } else {
             L.cur = LevelImg<LDS>{cur.data, cur.w, cur.h, cur.stride};
-            L.prev = LevelImg<LDS>{prev.data, prev.w, prev.h, prev.stride};
         }
+        L.prev = LevelImg<false>{prev.data, prev.w, prev.h, prev.stride};
         __syncthreads();
 
         // ---- per-level records that depend on the previous frame only
@@ -530,7 +526,7 @@ __device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, co
 }
 
 __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __restrict__ args,
-                                                              int max_img_bytes) {
+                                                              int max_img_bytes, int lds_bytes) {
     const SiaArgs& a = args[blockIdx.x];
     const int n = min(*a.n_ptr, a.cap);
     __shared__ SiaShared sh;
@@ -541,7 +537,7 @@ __global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __re
     const long long k0 = __builtin_readcyclecounter();
 #endif
     // the whole working set in LDS when this frame's keypoints fit, else the HBM workspace
-    if (max_img_bytes > 0 && lay.total <= SIA_LDS_BUDGET) sia_run<true>(a, n, sh, dyn, lay);
+    if (max_img_bytes > 0 && lay.total <= (size_t)lds_bytes) sia_run<true>(a, n, sh, dyn, lay);
     else sia_run<false>(a, n, sh, dyn, lay);
 #ifdef SVO_SIA_STAMPS
     if (threadIdx.x == 0 && a.dbg_H) {   // diagnostic build: the debug buffer carries cycle counts
@@ -563,23 +559,27 @@ static int sia_max_img_bytes(const svo_camera_settings& cam, int width, int heig
     return sia_lds_layout(64, best).total <= SIA_LDS_BUDGET ? best : 0;
 }
 
-size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap) {
-    (void)cap;
-    return sia_max_img_bytes(cam, width, height) > 0 ? SIA_LDS_BUDGET : 0;
+// Dynamic LDS of a launch: the working set of `n_bound` keypoints (the host's upper bound for every
+// sequence of the launch), not the whole budget, so that two or three alignment workgroups — or an
+// alignment workgroup and the window kernels of another sequence group — share a CU's 160 KB.
+size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int n_bound) {
+    const int img = sia_max_img_bytes(cam, width, height);
+    if (img <= 0) return 0;
+    const size_t need = sia_lds_layout(std::max(n_bound, 16), img).total;
+    return need <= SIA_LDS_BUDGET ? need : SIA_LDS_BUDGET;   // a sequence above the bound runs from HBM
 }
 
 void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
-                int height, int cap, hipStream_t stream) {
-    (void)cap;
-    static size_t configured = 0;
+                int height, int n_bound, hipStream_t stream) {
+    static std::atomic<size_t> configured{0};
     const int img = sia_max_img_bytes(cam, width, height);
-    const size_t lds_bytes = img > 0 ? SIA_LDS_BUDGET : 0;
-    if (lds_bytes > configured) {
+    const size_t lds_bytes = sia_lds_bytes(cam, width, height, n_bound);
+    if (lds_bytes > configured.load()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        configured = lds_bytes;
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIA_LDS_BUDGET);
+        configured.store(SIA_LDS_BUDGET);
     }
-    hipLaunchKernelGGL(sia_gn_kernel, dim3(batch), dim3(SIA_THREADS), lds_bytes, stream, d_args, img);
+    hipLaunchKernelGGL(sia_gn_kernel, dim3(batch), dim3(SIA_THREADS), lds_bytes, stream, d_args, img, (int)lds_bytes);
 }
 
 }  // namespace svo

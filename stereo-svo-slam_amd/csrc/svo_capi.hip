@@ -212,7 +212,7 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     SiaArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
-    launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, h->max_kps, h->stream);
+    launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

@@ -810,12 +810,13 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         SVO_MARK(1);
         launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
         SVO_MARK(2);
-        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, c->cap, c->stream);
-        SVO_MARK(3);
-        // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the grid
+        // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the
+        // grids and the alignment kernel's LDS working set
         int grid_n = 1;
         for (int s = 0; s < B; s++) grid_n = std::max(grid_n, c->seqs[s].n_host);
         grid_n = std::min(grid_n, c->cap);
+        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, grid_n, c->stream);
+        SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, grid_n, c->cam.window_size_opt_flow, c->stream);
         SVO_MARK(4);
         launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), B, c->stream);
@@ -1131,9 +1132,11 @@ svo_ctx::Worker* ctx_locate(svo_ctx* c, int seq, int* local) {
 extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
                               int device, svo_ctx** out) {
     if (!cam || !out || n_sequences < 1) return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
-    // SVO_GROUPS: number of independently driven groups (default 2 from 64 sequences on: measured
-    // +12 % at 64 and +20 % at 256 sequences on MI355X; more groups starve the alignment kernel)
-    int G = n_sequences >= 64 ? 2 : 1;
+    // SVO_GROUPS: number of independently driven groups. Default: groups of ~256 sequences (one
+    // alignment workgroup per CU), at least two from 64 sequences on. Measured on MI355X, 752x480:
+    // 256 sequences 129 K frames/s as one group, 153 K as two; 512: 173 K (2) / 176 K (3);
+    // 768: 188 K (3) / 169 K (4); 1024: 176 K (4).
+    int G = n_sequences >= 64 ? std::max(2, (n_sequences + 128) / 256) : 1;
     if (const char* e = std::getenv("SVO_GROUPS")) G = std::atoi(e);
     G = std::max(1, std::min(G, std::min(n_sequences, 16)));
     svo_ctx* c = new (std::nothrow) svo_ctx();

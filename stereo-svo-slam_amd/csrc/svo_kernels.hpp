@@ -47,7 +47,7 @@ struct SiaArgs {
 };
 void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int cap, hipStream_t stream);
-size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int cap);
+size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int n_bound);
 
 // --------------------------------------------------------------------- KLT
 struct KfDev {                    // one keyframe as the device sees it
