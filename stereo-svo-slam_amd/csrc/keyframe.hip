@@ -23,7 +23,7 @@
 namespace svo {
 
 // ------------------------------------------------------------ prefix scan
-// exclusive scan of one int per thread over the workgroup (1024 threads)
+// exclusive scan of one int per thread over the workgroup (any multiple of 64 threads)
 __device__ inline int block_exclusive_scan(int v, int* s_wave /*[16]*/, int& total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int inc = v;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
     __shared__ int s_wave[16];
     const int tid = threadIdx.x;
     const int n = *a.src.n;
-    const int per = (n + 1023) / 1024;
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
     const int i0 = tid * per, i1 = min(n, i0 + per);
     int cnt = 0;
     for (int i = i0; i < i1; i++) {
@@ -98,8 +98,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
     if (tid == 0) *a.dst.n = total;
 }
 
-void launch_compact(const CompactArgs* d_args, int batch, hipStream_t stream) {
-    hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(1024), 0, stream, d_args);
+// Small sets run with 256 threads: a 16-wave workgroup only starts on a CU that has drained, and
+// next to the other sequence groups' window kernels it waited ~0.4 ms for one (HIP events).
+void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(cap <= 1024 ? 256 : 1024), 0, stream, d_args);
 }
 
 // --------------------------------------------------------------- detection
@@ -253,7 +255,7 @@ void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_lev
 __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* __restrict__ args) {
     const MergeArgs& a = args[blockIdx.x];
     if (a.enable && !*a.enable) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int nsel = a.n_det[0];
     const int n_old = *a.kps.n;
     const int mcw = a.cam.grid_height, mch = a.cam.grid_width;   // swapped on purpose (:179-180)
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
     const int ncells = ncx * ncy;
 
     // select_best_keypoints: entry j of level i is compared with entry j of level 0
-    for (int j = tid; j < nsel; j += 1024) {
+    for (int j = tid; j < nsel; j += nthr) {
         DetCell s = a.det[j];
         int lvl = 0;
         for (int i = 1; i < a.n_levels; i++) {
@@ -278,10 +280,10 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
         a.sel_level[j] = lvl;
         a.sel_cell[j] = -1;
     }
-    for (int c = tid; c < ncells; c += 1024) a.occupied[c] = 0;
+    for (int c = tid; c < ncells; c += nthr) a.occupied[c] = 0;
     __syncthreads();
     // cells that already hold a keypoint (strictly inside)
-    for (int i = tid; i < n_old; i += 1024) {
+    for (int i = tid; i < n_old; i += nthr) {
         const svo_kp2d k = a.kps.kps2d[i];
         if (!(k.x > 0 && k.y > 0)) continue;
         const int xi = (int)floorf(k.x) / mcw, yi = (int)floorf(k.y) / mch;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
         if (k.x > l && k.x < l + mcw && k.y > t && k.y < t + mch) a.occupied[xi * ncy + yi] = 1;
     }
     __syncthreads();
-    for (int j = tid; j < nsel; j += 1024) {
+    for (int j = tid; j < nsel; j += nthr) {
         const DetCell s = a.sel[j];
         if (!(s.x > 0 && s.y > 0)) continue;
         const int xi = (int)floorf(s.x) / mcw, yi = (int)floorf(s.y) / mch;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
     __shared__ int s_cnt;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (int j = tid; j < nsel; j += 1024) {
+    for (int j = tid; j < nsel; j += nthr) {
         const int cj = a.sel_cell[j];
         if (cj < 0) continue;
         int pos = 0;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
     }
 }
 
-void launch_select_merge(const MergeArgs* d_args, int batch, hipStream_t stream) {
-    hipLaunchKernelGGL(kf_select_merge_kernel, dim3(batch), dim3(1024), 0, stream, d_args);
+void launch_select_merge(const MergeArgs* d_args, int batch, int max_cells, hipStream_t stream) {
+    hipLaunchKernelGGL(kf_select_merge_kernel, dim3(batch), dim3(max_cells <= 512 ? 256 : 1024), 0, stream, d_args);
 }
 
 // ------------------------------------------------------------------- init

@@ -671,10 +671,10 @@ static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool fi
     }
     if (m == 0) return SVO_OK;
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
-    launch_compact(dargs_at<CompactArgs>(c, c->off_compact), m, c->stream);
+    launch_compact(dargs_at<CompactArgs>(c, c->off_compact), m, c->cap, c->stream);
     if (c->det_levels > 0)
         launch_detect(dargs_at<DetectArgs>(c, c->off_det), m, c->max_cells, c->det_levels, c->stream);
-    launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), m, c->stream);
+    launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), m, c->max_cells, c->stream);
     launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), m, c->cap, c->stream);
     launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), m, c->stream);
     HIP_TRY(hipGetLastError());
@@ -808,7 +808,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         if ((rc = enqueue_keyframes(c, need, true))) return rc;
     } else {
         SVO_MARK(1);
-        launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->stream);
+        launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->cap, c->stream);
         SVO_MARK(2);
         // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the
         // grids and the alignment kernel's LDS working set

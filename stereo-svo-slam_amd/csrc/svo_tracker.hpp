@@ -31,7 +31,7 @@ struct CompactArgs {
     int width, height;
     const int* enable; // optional device predicate
 };
-void launch_compact(const CompactArgs* d_args, int batch, hipStream_t stream);
+void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t stream);
 
 struct DetCell {
     float x, y, score;
@@ -65,7 +65,7 @@ struct MergeArgs {
     int* overflow;
     const int* enable;
 };
-void launch_select_merge(const MergeArgs* d_args, int batch, hipStream_t stream);
+void launch_select_merge(const MergeArgs* d_args, int batch, int max_cells, hipStream_t stream);
 
 struct KfInitArgs {
     svo_camera_settings cam;

@@ -17,13 +17,15 @@ python3 - "$OUT" "$@" <<'PY'
 import csv, json, sys, collections
 out = sys.argv[1]
 args = sys.argv[2:]
-seqs = int(args[args.index("--seqs") + 1]) if "--seqs" in args else 256
+bj = json.loads(open(f"{out}/bench_FETCH_SIZE.json").read().strip().splitlines()[-1])
+seqs, groups = bj["config"]["sequences_per_gpu"], bj["config"]["sequence_groups"]
 cfg = args[args.index("--config") + 1] if "--config" in args else "euroc"
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f"/tmp/pmc_{c}.csv")):
-        agg[r["Kernel_Name"].split("(")[0].replace("svo::", "")].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("svo::", "").split("<")[0]
+        agg[name].append(float(r["Counter_Value"]))
     with open(f"{out}/{c.lower()}.csv", "w") as f:
         f.write("kernel,dispatches,mean_KB,max_KB\n")
         for k, v in sorted(agg.items()):
@@ -35,7 +37,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # guide leaves uncalibrated, so the raw value is kept and the x2 upper bound is stored beside it.
 traffic = {k: (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in res.items()}
 upper = {k: (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in res.items()}
-json.dump({"seqs": seqs, "config": cfg, "bytes_per_launch": traffic, "bytes_per_launch_fetch_x2": upper,
+json.dump({"seqs": seqs, "groups": groups, "config": cfg, "bytes_per_launch": traffic, "bytes_per_launch_fetch_x2": upper,
            "note": "mean over all dispatches of the run; FETCH_SIZE and WRITE_SIZE from separate --pmc passes"},
           open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
