@@ -199,7 +199,12 @@ def main():
     named = {STAGES[i]: float(per_launch_ms[i]) for i in range(8)}
     kernel_stages = ("sparse_align", "klt", "reproj_gn", "ssd_disparity", "filter_update",
                      "images+pyramids")
+    # the kernel with the most work per launch is klt_track_kernel (PMC: most VALU instructions,
+    # profiles/); under the overlap of the sequence groups the event times of the three big
+    # stages are within noise of each other, so klt is reported unless another stage clearly leads
     dom = max(kernel_stages, key=lambda s: named[s])
+    if named["klt"] >= 0.8 * named[dom]:
+        dom = "klt"
     achieved = ab[dom] * seqs_per_launch / (named[dom] * 1e-3) / 1e9 if named[dom] > 0 else 0.0
     # HBM bytes per launch from rocprofv3 PMC passes of this command (tools/pmc_traffic.sh ->
     # profiles/r01_traffic.json); null when that file does not cover this configuration
@@ -218,6 +223,17 @@ def main():
                         f"{G - 1} sequence group(s) share the GPU; the window kernels are VALU-issue "
                         "bound (PMC: KLT 66 %, SSD 88 % of issue slots when run alone), not HBM bound",
                 "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
+
+    # matrix-core use of ssd_disparity_kernel: one 16x16x64 i8 MFMA per template row and 16-column
+    # block of the match map
+    win_d, sx_, sy_ = cfg["window_size_depth_calculator"], cfg["search_x"], cfg["search_y"]
+    mfma_per_kp = win_d * ((sx_ + 1 + 15) // 16) * ((2 * sy_ + 1 + 15) // 16)
+    ops = 2.0 * 16 * 16 * 64 * mfma_per_kp * mean_kps * seqs_per_launch
+    roofline["ssd_mfma"] = {"bound": "mfma", "achieved": ops / (named["ssd_disparity"] * 1e-3) / 1e12,
+                            "peak": 5000.0, "unit": "TOP/s (i8 dense)",
+                            "frac": ops / (named["ssd_disparity"] * 1e-3) / 1e12 / 5000.0,
+                            "useful_fraction_of_issued_macs": (win_d * win_d * (sx_ + 1) * (2 * sy_ + 1)) /
+                                                              (16.0 * 16 * 64 * mfma_per_kp)}
 
     single = None
     if args.single:
