@@ -124,3 +124,25 @@ def test_two_rank_gloo_run(tmp_path):
         for k in range(4):
             s.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
         assert np.allclose(row[2:], s.pose(), atol=0)
+
+
+def test_cpp_facade_builds_and_fails_loudly_without_gpu(tmp_path):
+    """The C++ facade (reference class and method names, hostcpp/stereo_slam.hpp) compiles and links
+    against libsvo_hip.so; without a GPU StereoSlam::new_image throws the library's error text
+    instead of computing anything on the CPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "stereo-svo-slam_amd", "csrc")
+    exe = str(tmp_path / "facade_smoke")
+    gxx = shutil.which("g++")
+    assert gxx
+    subprocess.check_call([gxx, "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "facade_smoke.cpp"),
+                           "-o", exe, "-L" + csrc, "-lsvo_hip", "-Wl,-rpath," + csrc,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "keypoints" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    else:
+        assert r.returncode == 3 and "no HIP device" in r.stdout, (r.returncode, r.stdout, r.stderr)
