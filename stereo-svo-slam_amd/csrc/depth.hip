@@ -41,7 +41,10 @@ constexpr int SSD_R_STRIDE = 144;               // bytes per search-region row (
 constexpr int SSD_R_ROWS = SSD_MAX_WIN + SSD_MAX_MH;   // 52
 constexpr int SSD_W_STRIDE = 100;               // ints per row of the column sums
 constexpr int SSD_MAX_MATCH = SSD_MAX_MW * SSD_MAX_MH;
-constexpr int SSD_THREADS = 256;
+#ifndef SVO_SSD_THREADS
+#define SVO_SSD_THREADS 256
+#endif
+constexpr int SSD_THREADS = SVO_SSD_THREADS;
 
 typedef int ssd_v4i __attribute__((ext_vector_type(4)));
 
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     __syncthreads();
 
     // ---- sum T^2 (wave 3) and the column sums W[k][x] = sum_{r<th} R[k+r][x]^2 (one thread per column)
-    if (wave == 3) {
+    if (wave == SSD_THREADS / 64 - 1) {
         int tt = 0;
         if (lane < th) {
             const uint32_t* trow = reinterpret_cast<const uint32_t*>(s_t + lane * SSD_T_STRIDE) + 4;
@@ -153,9 +156,11 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     // ---- cross term on the matrix cores: wave -> (row block, column block) of the match map
     const int n_jb = (mw + 15) >> 4, n_mb = (mh + 15) >> 4;
     const int fm = lane & 15, fh = lane >> 4;        // fragment row / column and 16-byte k slice
-    constexpr int SSD_SLOTS = 3;                     // <= 2 x 5 blocks over 4 waves
-    ssd_v4i acc[SSD_SLOTS] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    int task_of[SSD_SLOTS] = {-1, -1, -1};
+    constexpr int SSD_SLOTS = (10 + SSD_THREADS / 64 - 1) / (SSD_THREADS / 64);   // <= 2 x 5 blocks over the waves
+    ssd_v4i acc[SSD_SLOTS];
+    int task_of[SSD_SLOTS];
+#pragma unroll
+    for (int t = 0; t < SSD_SLOTS; t++) { acc[t] = ssd_v4i{0, 0, 0, 0}; task_of[t] = -1; }
     {
         int slot = 0;
         for (int task = wave; task < n_jb * n_mb && slot < SSD_SLOTS; task += SSD_THREADS / 64, slot++) {
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     // ---- window sums of R^2: rows of W, 8 sliding segments per map row -> s_m
     {
         const int seg_len = (mw + 7) >> 3;
-        if (tid < mh * 8) {
-            const int k = tid >> 3, j0 = (tid & 7) * seg_len, j1 = min(mw, j0 + seg_len);
+        for (int item = tid; item < mh * 8; item += SSD_THREADS) {
+            const int k = item >> 3, j0 = (item & 7) * seg_len, j1 = min(mw, j0 + seg_len);
             if (j0 < j1) {
                 const int* wrow = &s_w[k * SSD_W_STRIDE];
                 int sq = 0;
