@@ -116,8 +116,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--seqs", type=int, default=768,
-                    help="sequences per GPU (default: three groups of 256 = one alignment workgroup per CU each)")
+    ap.add_argument("--seqs", type=int, default=None,
+                    help="sequences per GPU (default 768: three groups of 256 = one alignment workgroup "
+                         "per CU each; fewer when steps + warmup would need more than ~40 K synthetic frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm", type=float, default=1.5,
                     help="seconds of untimed load on a throw-away ctx before the warm-up steps (clock ramp)")
@@ -138,8 +139,12 @@ def main():
     device = torch.device("cuda", local_rank if (world > 1 and not args.share_gpu) else 0)
     torch.cuda.set_device(device)
 
-    B, K, Wm = args.seqs, args.steps, max(args.warmup, 1)
+    K, Wm = args.steps, max(args.warmup, 1)
     n_frames = Wm + K
+    if args.seqs is None:
+        # every sequence needs its own n_frames rendered stereo pairs (0.72 MB each, ~3 ms to render)
+        args.seqs = 768 if 768 * n_frames <= 40000 else max(256, (40000 // n_frames) // 256 * 256)
+    B = args.seqs
     seq_ids = multi_seq.sequence_ids(rank, world, B)
     t_setup = time.perf_counter()
     cfg, lefts, rights, ts = render_sequences(args.config, seq_ids, n_frames, device)
