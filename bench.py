@@ -126,6 +126,9 @@ def main():
                     help="process-group backend for --gpus > 1 (default nccl = RCCL). gloo + "
                          "--share-gpu rehearses the multi-rank path on a single-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="frames start in pinned host memory (SVO_MEM_HOST): the PCIe-inclusive rate that "
+                         "DESIGN.md quotes beside `value`; never the headline number")
     ap.add_argument("--single", action="store_true",
                     help="also time one sequence alone (latency leg; off by default so that a "
                          "rocprofv3 --stats run of the default command sees only the batched launches)")
@@ -165,6 +168,17 @@ def main():
             warm.wait()
         warm.close()
         del warm, wp
+
+    if args.host_input:      # one pinned [B][H][W] block per frame index and side; the device copies go
+        def to_host(frames):
+            blocks = [torch.empty((B,) + tuple(frames[0][0].shape), dtype=torch.uint8).pin_memory()
+                      for _ in range(n_frames)]
+            for s in range(B):
+                for k in range(n_frames):
+                    blocks[k][s].copy_(frames[s][k])
+            return [[blocks[k][s] for k in range(n_frames)] for s in range(B)]
+        lefts, rights = to_host(lefts), to_host(rights)
+        torch.cuda.empty_cache()
 
     slam = StereoSlamBatch(cfg, cfg["width"], cfg["height"], B, device.index)
     slam.enable_timing(True)
@@ -229,6 +243,12 @@ def main():
                         "bound (PMC: KLT 66 %, SSD 88 % of issue slots when run alone), not HBM bound",
                 "frame_GBps_all_stages": sum(ab.values()) * fps / world / 1e9}
 
+    # the streaming stage (the one HBM-bound part of the path): ingest + both pyramids, 3 launches
+    hbm_ms = named["images+pyramids"]
+    roofline["pyramids_hbm"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                "achieved": ab["images+pyramids"] * seqs_per_launch / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else 0.0,
+                                "note": "algorithmic bytes B_P of DESIGN.md section 5 (reads + writes of every level once) / event time of the stage"}
+    roofline["pyramids_hbm"]["frac"] = roofline["pyramids_hbm"]["achieved"] / HBM_PEAK_GBS
     # matrix-core use of ssd_disparity_kernel: one 16x16x64 i8 MFMA per template row and 16-column
     # block of the match map
     win_d, sx_, sy_ = cfg["window_size_depth_calculator"], cfg["search_x"], cfg["search_y"]
@@ -270,7 +290,7 @@ def main():
         "metric": "tracked_frames_per_sec", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" + (" (frames copied from pinned host memory inside the timed region)" if args.host_input else ""),
         "config": {"workload": f"{args.config}: EuRoC MH_02 class {cfg['width']}x{cfg['height']} stereo, "
                                f"{cfg['max_pyramid_levels'] - cfg['min_pyramid_level_pose_estimation']}-level SIA pyramid, "
                                f"{mean_kps:.0f} patches/frame (synthetic, seeded)",

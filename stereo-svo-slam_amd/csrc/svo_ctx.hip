@@ -288,6 +288,9 @@ struct svo_group {
     // d_res | d_n_all | d_inside are one device block mirrored by one pinned block: the end-of-frame
     // read-back is a single copy, the keyframe decision reads back only the B inside-counters
     int* d_inside = nullptr; int* h_inside = nullptr;
+    // host-resident input frames land here first (2 x B frames; runs of contiguous frames as one
+    // copy) and are then ingested like device-resident ones
+    uint8_t* d_stage_in = nullptr; size_t stage_frame_bytes = 0;
     size_t readback_bytes = 0;
     size_t sia_lds = 0;
     bool timing = false;
@@ -688,7 +691,6 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
     HIP_TRY(hipSetDevice(c->device));
     const auto wall0 = std::chrono::steady_clock::now();
     const int B = c->B;
-    const hipMemcpyKind kind = mem == SVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const bool first = c->seqs[0].frame_id < 0;
     int rc;
 #define SVO_MARK(i) do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[i], c->stream)); } while (0)
@@ -701,6 +703,35 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
     SVO_MARK(0);
 
     // ---- images in, pyramids
+    if (mem != SVO_MEM_DEVICE) {
+        const size_t used = (size_t)(c->height - 1) * stride + c->width;      // bytes of one frame that are read
+        const size_t fb = align_up((size_t)c->height * stride, 256);
+        if (fb > c->stage_frame_bytes) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if ((rc = dev_alloc(c, &c->d_stage_in, fb * 2 * B))) return rc;    // (an outgrown buffer is freed with the ctx)
+            c->stage_frame_bytes = fb;
+        }
+        // slots 0..B-1: left frames, B..2B-1: right frames. Host frames that follow each other at
+        // exactly one frame's distance (one [B][H][stride] block per side) go as ONE 2D copy:
+        // a "row" is a whole frame
+        const size_t spacing = (size_t)c->height * stride;
+        for (int side = 0; side < 2; side++) {
+            const uint8_t* const* src = side ? right : left;
+            int s0 = 0;
+            while (s0 < B) {
+                int s1 = s0 + 1;
+                while (s1 < B && src[s1] == src[s1 - 1] + spacing) s1++;
+                uint8_t* dst = c->d_stage_in + (size_t)(side * B + s0) * c->stage_frame_bytes;
+                if (s1 - s0 > 1) {
+                    HIP_TRY(hipMemcpy2DAsync(dst, c->stage_frame_bytes, src[s0], spacing, spacing, s1 - s0,
+                                             hipMemcpyHostToDevice, c->stream));
+                } else {
+                    HIP_TRY(hipMemcpyAsync(dst, src[s0], used, hipMemcpyHostToDevice, c->stream));
+                }
+                s0 = s1;
+            }
+        }
+    }
     for (int s = 0; s < B; s++) {
         Seq& q = c->seqs[s];
         release_set(q, q.prev_set);
@@ -711,18 +742,13 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         std::memset(hs, 0, sizeof(*hs));
         hs->n_levels = c->cam.max_pyramid_levels;
         for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
-        if (mem == SVO_MEM_DEVICE) {
-            // device-resident frames are ingested by the pyramid kernel itself (one launch
-            // for all sequences instead of 2 copies per sequence)
-            hs->src_left = ImgView{left[s], c->width, c->height, stride};
-            hs->src_right = ImgView{right[s], c->width, c->height, stride};
-            hs->dst_right = is->right;
-        } else {
-            HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->left[0].data), is->left[0].stride, left[s],
-                                     stride, c->width, c->height, kind, c->stream));
-            HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(is->right.data), is->right.stride, right[s],
-                                     stride, c->width, c->height, kind, c->stream));
-        }
+        // frames are ingested by the pyramid kernel itself (one launch for all sequences instead of
+        // 2 copies per sequence); host-resident ones come through the staging buffer filled above
+        const uint8_t* src_l = mem == SVO_MEM_DEVICE ? left[s] : c->d_stage_in + (size_t)s * c->stage_frame_bytes;
+        const uint8_t* src_r = mem == SVO_MEM_DEVICE ? right[s] : c->d_stage_in + (size_t)(c->B + s) * c->stage_frame_bytes;
+        hs->src_left = ImgView{src_l, c->width, c->height, stride};
+        hs->src_right = ImgView{src_r, c->width, c->height, stride};
+        hs->dst_right = is->right;
         PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, s);
         std::memset(lk, 0, sizeof(*lk));
         lk->n_levels = c->n_lk;
@@ -789,8 +815,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
     }
     hlap(0);   // argument blocks
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
-    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height,
-                          mem == SVO_MEM_DEVICE, c->stream);
+    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height, true, c->stream);
     {
         int w = c->width, h = c->height;
         for (int l = 0; l + 1 < c->n_lk; l++) {

@@ -115,26 +115,28 @@ class StereoSlamBatch:
         _check(lib().svo_new_images(self._ctx, ptrs_l, ptrs_r, stride, ts, 1 if on_dev else 0))
 
     def pack_images(self, lefts, rights, time_stamps):
-        """Pre-build the argument arrays of one step for device-resident frames
-        (keeps Python out of a timed loop); pass the result to new_images_packed."""
+        """Pre-build the argument arrays of one step (keeps Python out of a timed loop); pass the
+        result to new_images_packed / submit_packed. The frames are torch uint8 tensors, all on
+        the GPU (SVO_MEM_DEVICE) or all in host memory (SVO_MEM_HOST; pinned for full PCIe rate)."""
         ptrs_l = (C.c_void_p * self.n)()
         ptrs_r = (C.c_void_p * self.n)()
         stride = lefts[0].stride(0)
+        on_dev = lefts[0].is_cuda
         for s in range(self.n):
             for arr, dst in ((lefts[s], ptrs_l), (rights[s], ptrs_r)):
-                assert arr.is_cuda and arr.dtype == torch.uint8 and arr.stride(1) == 1
+                assert arr.is_cuda == on_dev and arr.dtype == torch.uint8 and arr.stride(1) == 1
                 assert tuple(arr.shape) == (self.height, self.width) and arr.stride(0) == stride
                 dst[s] = arr.data_ptr()
         ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
-        return ptrs_l, ptrs_r, stride, ts, (lefts, rights)
+        return ptrs_l, ptrs_r, stride, ts, (lefts, rights), 1 if on_dev else 0
 
     def new_images_packed(self, packed):
-        _check(lib().svo_new_images(self._ctx, packed[0], packed[1], packed[2], packed[3], 1))
+        _check(lib().svo_new_images(self._ctx, packed[0], packed[1], packed[2], packed[3], packed[5]))
 
     def submit_packed(self, packed):
         """Pipelined form (svo_submit_images): queues the frame set on every sequence group and
         returns; `packed` (and its device images) must stay alive until wait()."""
-        _check(lib().svo_submit_images(self._ctx, packed[0], packed[1], packed[2], packed[3], 1))
+        _check(lib().svo_submit_images(self._ctx, packed[0], packed[1], packed[2], packed[3], packed[5]))
 
     def wait(self):
         _check(lib().svo_wait(self._ctx))
