@@ -81,9 +81,10 @@ def render_sequences(cfg_name, seq_ids, n_frames, device):
     return cfg, lefts, rights, ts
 
 
-def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0):
+def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0, gpu_trajectory=None):
     """The CPU oracle (oracle/, single thread) on the first sequence: frames/s with the
-    reference's formula (time inside new_image only, src/app/slam_app.cpp:186-190)."""
+    reference's formula (time inside new_image only, src/app/slam_app.cpp:186-190). As the
+    checker it also compares its pose after every frame with the GPU trajectory of that sequence."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     cam = O.make_camera(**{k: cfg[k] for k in synth.CAMERA_FIELDS})
@@ -91,10 +92,13 @@ def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0):
     n = min(max_frames, len(lefts))
     host = [(lefts[k].cpu().numpy(), rights[k].cpu().numpy()) for k in range(n)]
     t_total, done, n_grad, t_sia = 0.0, 0, 0, 0.0
+    max_diff, kf_cpu = 0.0, 0
     for k in range(n):
         t0 = time.perf_counter()
-        slam.new_image(host[k][0], host[k][1], float(ts[k]))
+        kf_cpu += int(slam.new_image(host[k][0], host[k][1], float(ts[k])))
         dt = time.perf_counter() - t0
+        if gpu_trajectory is not None and k < len(gpu_trajectory):
+            max_diff = max(max_diff, float(np.max(np.abs(np.asarray(slam.pose()) - gpu_trajectory[k]))))
         if k > 0:                       # like the GPU leg: the first (keyframe) frame is warm-up
             t_total += dt
             done += 1
@@ -107,7 +111,11 @@ def cpu_baseline(cfg, lefts, rights, ts, max_frames, budget_s=25.0):
             "kind": "port",
             "sample": f"oracle/ (C restatement, gcc -O3, 1 thread) on sequence 0, frames 1..{done} "
                       f"of the same synthetic workload",
-            "gn_ms_per_iter": 1e3 * t_sia / max(n_grad, 1)}
+            "gn_ms_per_iter": 1e3 * t_sia / max(n_grad, 1),
+            "parity": None if gpu_trajectory is None else
+            {"frames_compared": min(done + 1, len(gpu_trajectory)), "max_abs_pose_diff": max_diff,
+             "tolerance": 1e-4, "keyframes_cpu": kf_cpu,
+             "note": "oracle pose after each frame vs the HIP trajectory of sequence 0 (m / rad)"}}
 
 
 def main():
@@ -284,7 +292,7 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline(cfg, lefts[0], rights[0], ts, n_frames)
+        cpu = cpu_baseline(cfg, lefts[0], rights[0], ts, n_frames, gpu_trajectory=np.asarray(slam.get_trajectory(0)))
 
     out = {
         "metric": "tracked_frames_per_sec", "value": fps, "unit": "frames/s",
