@@ -24,11 +24,12 @@ def _compare_frame(tag, gpu_frame, ok2, ok3, oinfo, pose_ref, tol=1e-4):
     assert np.array_equal(gpu_frame.info["score"], oinfo["score"]), f"{tag}: score"
     assert np.max(np.abs(gpu_frame.pose - pose_ref)) < tol, (tag, gpu_frame.pose, pose_ref)
     if len(ok2):
-        assert np.max(np.abs(gpu_frame.kps2d - ok2)) < 5e-2, f"{tag}: kps2d"
-        assert np.max(np.abs(gpu_frame.kps3d - ok3)) < 5e-3, f"{tag}: kps3d"
+        loose = tol > 1e-4                                   # stress sequence: positions follow the pose
+        assert np.max(np.abs(gpu_frame.kps2d - ok2)) < (0.3 if loose else 5e-2), f"{tag}: kps2d"
+        assert np.max(np.abs(gpu_frame.kps3d - ok3)) < (2e-2 if loose else 5e-3), f"{tag}: kps3d"
 
 
-def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False):
+def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False, tol=1e-4):
     cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device="cpu",
                                                motion_scale=motion_scale)
     cam = util.oracle_camera(cfg)
@@ -47,7 +48,7 @@ def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False)
         st = gpu.stats()
         assert st.is_keyframe == made, f"frame {k}: keyframe decision"
         ok2, ok3, oinfo = ref.keypoints()
-        _compare_frame(f"{config}/{seed} frame {k}", gpu.get_frame(), ok2, ok3, oinfo, ref.pose())
+        _compare_frame(f"{config}/{seed} frame {k}", gpu.get_frame(), ok2, ok3, oinfo, ref.pose(), tol)
     assert gpu.num_keyframes() == ref.num_keyframes() == n_kf
     for kid in range(n_kf):
         k2, k3, info, pose = ref.keyframe(kid)
@@ -107,6 +108,18 @@ def test_sequence_with_keyframe_creation():
     """Fast motion so that keyframe_needed fires inside the sequence."""
     gpu, ref = _run("tiny", 30, 1, motion_scale=4.0)
     assert ref.num_keyframes() >= 2
+
+
+def test_long_sequence_with_keyframes_at_full_size():
+    """Stress case: 60 frames of the C2 configuration at 3x the motion, several keyframes inside the
+    sequence. Feature index lists, flags and counters stay bit-exact on every frame. The pose bound is
+    looser here than the 1e-4 of the other sequences: both Gauss-Newton loops stop on cost changes at
+    float32 resolution (cost ~6000), so a different summation order changes iteration counts now
+    and then (tools/parity_trace.py: e.g. 14 vs 12 alignment steps at frame 38), the poses drift
+    apart by up to ~1e-3 for a few frames and re-converge (1.5e-5 again five frames later)."""
+    gpu, ref = _run("euroc", 60, 5, motion_scale=3.0, tol=3e-3)
+    assert ref.num_keyframes() >= 3
+    assert np.max(np.abs(gpu.get_frame().pose - ref.pose())) < 5e-4
 
 
 def test_device_resident_input():
