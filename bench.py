@@ -33,6 +33,8 @@ from stereo_svo_slam_amd import multi_seq, synth
 from stereo_svo_slam_amd.stereo_slam import StereoSlamBatch
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOAD_LABEL = {"euroc": "EuRoC MH_02 class (C2)", "blender": "Blender classroom class (C1)",
+                  "hd": "synthetic roofline case (C3)", "econ": "Econ Tara class, distorted (C5)", "tiny": "test size"}
 KERNEL_OF_STAGE = {"sparse_align": "sia_gn_kernel", "klt": "klt_track_kernel",
                    "reproj_gn": "reproj_gn_kernel", "ssd_disparity": "ssd_disparity_kernel",
                    "filter_update": "filter_update_kernel", "images+pyramids": "pyr_halfsample_kernel"}
@@ -299,7 +301,7 @@ def main():
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" + (" (frames copied from pinned host memory inside the timed region)" if args.host_input else ""),
-        "config": {"workload": f"{args.config}: EuRoC MH_02 class {cfg['width']}x{cfg['height']} stereo, "
+        "config": {"workload": f"{args.config}: {WORKLOAD_LABEL.get(args.config, 'synthetic')} {cfg['width']}x{cfg['height']} stereo, "
                                f"{cfg['max_pyramid_levels'] - cfg['min_pyramid_level_pose_estimation']}-level SIA pyramid, "
                                f"{mean_kps:.0f} patches/frame (synthetic, seeded)",
                    "sequences_per_gpu": B, "frames_per_step": B * world,
