@@ -168,12 +168,12 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
     }
 }
 
-// CW: threads per window row (32 when w+1 <= 32, else 64); a thread owns column lc and
-// the RPT consecutive rows starting at lr*RPT.
+// CW: threads per window row: 32 when w+1 <= 32 (4 row groups of 8 rows), else 36 (3 row groups of
+// 12 rows, 108 of the 128 threads). A thread owns column lc and the RPT consecutive rows from lr*RPT.
 template <int CW>
 __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* __restrict__ args) {
     constexpr int NG = KLT_THREADS / CW;                               // row groups
-    constexpr int ROWS = CW == 32 ? 32 : KLT_DW;                        // tap rows to cover
+    constexpr int ROWS = CW;                                            // tap rows to cover (w+1 <= CW)
     constexpr int RPT = (((ROWS + NG - 1) / NG) + 1) & ~1;              // even: rows are kept as pairs
     constexpr int NPAIR = RPT / 2;
     const KltArgs& a = args[blockIdx.y];
@@ -183,8 +183,9 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     const int tid = threadIdx.x;
     const int win = a.win;
     const int RW = win + 3, DW = win + 1, TJ = DW + 2 * KLT_MARGIN;
-    const int lc = tid & (CW - 1), lr = tid / CW;
-    const int y0 = lr * RPT;
+    const int lr = tid / CW, lc = tid - lr * CW;
+    const bool row_on = lr < NG;                 // CW = 36: the last 20 threads only help with the tiles
+    const int y0 = row_on ? lr * RPT : 0;
 
     __shared__ __attribute__((aligned(16))) uint8_t s_I[KLT_RROWS * KLT_RS];
     __shared__ int s_d[(KLT_DW + 1) * KLT_DW];    // packed (dx, dy) int16; + one slack row
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     epsilon *= epsilon;
     int status = 1;
     float err = 0;
-    const bool col_on = lc < win;
+    const bool col_on = row_on && lc < win;
 
     for (int level = maxLevel; level >= 0; level--) {
         const ImgView I = kf.lk[level];
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions, sliding down the thread's rows:
         // hd = p[+1]-p[-1], hs = 3(p[-1]+p[+1]) + 10 p[0] per tile row; dx = 3(hd_0+hd_2) + 10 hd_1,
         // dy = hs_2 - hs_0. Zero outside the image.
-        if (lc < DW) {
+        if (lc < DW && row_on) {
             const int gx = iprevx + lc;
             const bool xin = (unsigned)gx < (unsigned)I.w;
             const uint32_t pcol = lds_addr(&s_I[y0 * KLT_RS + ox + lc]);
@@ -436,7 +437,7 @@ void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_
     if (win + 1 <= 32)
         hipLaunchKernelGGL(klt_track_kernel<32>, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
     else
-        hipLaunchKernelGGL(klt_track_kernel<64>, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
+        hipLaunchKernelGGL(klt_track_kernel<36>, dim3(max_n, batch), dim3(KLT_THREADS), 0, stream, d_args);
 }
 
 }  // namespace svo
