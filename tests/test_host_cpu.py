@@ -146,3 +146,29 @@ def test_cpp_facade_builds_and_fails_loudly_without_gpu(tmp_path):
         assert r.returncode == 0 and "keypoints" in r.stdout, (r.returncode, r.stdout, r.stderr)
     else:
         assert r.returncode == 3 and "no HIP device" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_timed_steps_runs_finish_fn_inside_the_timed_region():
+    """Queued steps (svo_submit_images) are drained by finish_fn before the clock stops: once after
+    the warm-up steps and once after the timed ones."""
+    calls = []
+    dt = multi_seq.timed_steps(lambda k: calls.append(("step", k)), 3, 2, 1, None,
+                               finish_fn=lambda: calls.append(("finish",)))
+    assert dt >= 0
+    assert calls == [("step", 0), ("step", 1), ("finish",), ("step", 2), ("step", 3), ("step", 4), ("finish",)]
+
+
+def test_bench_algorithmic_bytes_follow_design_section_5():
+    """bench.algorithmic_bytes restates DESIGN.md section 5 / SURVEY 8d for the C2 configuration."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = synth.CONFIGS["euroc"]
+    n = 150
+    ab = bench.algorithmic_bytes(cfg, n, n)
+    W, H = 752, 480
+    b_p = 2 * W * H + sum((W >> l) * (H >> l) for l in range(1, 6)) + 376 * 240 + 188 * 120
+    assert ab["images+pyramids"] == b_p
+    assert ab["sparse_align"] == 4 * n * 120
+    assert ab["klt"] == n * 3 * 2 * 33 * 33 + 21 * n
+    assert ab["ssd_disparity"] == n * (31 * 31 + (31 + 60) * (31 + 12)) + 12 * n
+    assert ab["reproj_gn"] == 24 * n and ab["filter_update"] == 64 * n
