@@ -279,7 +279,7 @@ struct svo_group {
     hipStream_t stream;
     std::vector<Seq> seqs;
     // argument blocks: pinned host mirror + device copy, one array per kernel
-    uint8_t* h_args = nullptr; uint8_t* d_args = nullptr; size_t args_bytes = 0;
+    uint8_t* h_args = nullptr; uint8_t* d_args = nullptr; size_t args_bytes = 0, frame_args_bytes = 0;
     size_t off_hs, off_lk, off_compact, off_sia, off_klt, off_rp, off_ssd, off_filt, off_det,
         off_merge, off_init, off_guess, off_enable, off_kfdev;
     FrameResult* d_res = nullptr; FrameResult* h_res = nullptr;
@@ -516,10 +516,11 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     c->off_rp = reserve(sizeof(ReprojArgs) * B);
     c->off_ssd = reserve(sizeof(SsdArgs) * B);
     c->off_filt = reserve(sizeof(FilterArgs) * B);
+    c->off_guess = reserve(sizeof(float) * 8 * B);
+    c->frame_args_bytes = off;                    // everything a tracked frame uploads; the rest is keyframe-only
     c->off_det = reserve(sizeof(DetectArgs) * B);
     c->off_merge = reserve(sizeof(MergeArgs) * B);
     c->off_init = reserve(sizeof(KfInitArgs) * B);
-    c->off_guess = reserve(sizeof(float) * 8 * B);
     c->off_enable = reserve(sizeof(int) * B);
     c->off_kfdev = reserve(sizeof(KfDev) * B);
     c->args_bytes = off;
@@ -814,7 +815,8 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         for (int s = 0; s < B; s++) fill(s);   // ~20 us for 256 sequences: not worth waking the pool
     }
     hlap(0);   // argument blocks
-    HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, first ? c->args_bytes : c->frame_args_bytes,
+                           hipMemcpyHostToDevice, c->stream));
     launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height, true, c->stream);
     {
         int w = c->width, h = c->height;
