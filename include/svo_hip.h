@@ -100,8 +100,8 @@ int svo_depth_filter_update(svo_handle *h, const svo_kp2d *kps2d, svo_kp3d *kps3
                             int do_outlier_check, int do_update);
 
 /* ---- whole tracker: StereoSlam (src/include/stereo_slam.hpp:27-79) --------
- * One svo_ctx owns `n_sequences` independent StereoSlam instances that advance
- * in lock-step and share every kernel launch (sequence = a grid dimension);
+ * One svo_ctx owns `n_sequences` independent StereoSlam instances; the sequences of
+ * a group share every kernel launch (sequence = a grid dimension);
  * n_sequences = 1 is the drop-in for one StereoSlam object. A ctx is
  * single-caller; different ctxs are independent (own stream, own counters —
  * the reference's process-global keyframe counters, keyframe_manager.cpp:8 and
@@ -122,9 +122,8 @@ int svo_ctx_destroy(svo_ctx *ctx);
  * after the frame is complete (like the reference). */
 int svo_new_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *const *right,
                    int stride, const float *time_stamps, int mem);
-/* n_sequences == 1, host memory: the exact shape of StereoSlam::new_image */
-/* Pipelined form: svo_submit_images() queues one frame set (same arguments; device-resident
- * images must stay valid until svo_wait) on every sequence group and returns; svo_wait()
+/* Pipelined form (no counterpart in the reference, whose new_image is synchronous): svo_submit_images() queues one frame set (same arguments; the images,
+ * host or device, must stay valid until svo_wait) on every sequence group and returns; svo_wait()
  * blocks until all queued frame sets are processed and reports the first error. The groups
  * (svo_ctx_get_groups; SVO_GROUPS overrides the default) advance independently, each on its
  * own HIP stream and host thread, so one group's host round trips (keyframe decision,
@@ -134,6 +133,7 @@ int svo_submit_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *c
                       int stride, const float *time_stamps, int mem);
 int svo_wait(svo_ctx *ctx);
 int svo_ctx_get_groups(svo_ctx *ctx, int *n_groups);
+/* n_sequences == 1, host memory: the exact shape of StereoSlam::new_image */
 int svo_new_image(svo_ctx *ctx, const uint8_t *left, int left_stride, const uint8_t *right,
                   int right_stride, int width, int height, float time_stamp);
 
