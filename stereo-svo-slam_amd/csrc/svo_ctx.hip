@@ -1,5 +1,7 @@
-// svo_group.hip — the tracker behind the C ABI: StereoSlam::new_image
-// (src/lib/stereo_slam.cpp:123-271) for B sequences in lock-step.
+// svo_ctx.hip — the tracker behind the C ABI: StereoSlam::new_image
+// (src/lib/stereo_slam.cpp:123-271). A group (svo_group, first part of this file) advances B
+// sequences together, one kernel launch per stage; the public svo_ctx (end of the file) is a set of
+// groups, each on its own stream and host thread, with a queue of submitted frame sets.
 //
 // Host side = bookkeeping only: image-set pool, argument blocks, the 12-state
 // pose Kalman filter (stereo_slam.cpp:296-359) and the keyframe decision. All
