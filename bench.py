@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="frames start in pinned host memory (SVO_MEM_HOST): the PCIe-inclusive rate that "
                          "DESIGN.md quotes beside `value`; never the headline number")
+    ap.add_argument("--exact", action="store_true",
+                    help="reference-order mode (svo_ctx_set_exact_pinv): sequential normal equations + SVD inverse")
     ap.add_argument("--single", action="store_true",
                     help="also time one sequence alone (latency leg; off by default so that a "
                          "rocprofv3 --stats run of the default command sees only the batched launches)")
@@ -192,6 +194,7 @@ def main():
 
     slam = StereoSlamBatch(cfg, cfg["width"], cfg["height"], B, device.index)
     slam.enable_timing(True)
+    slam.set_exact_pinv(args.exact)
     packed = [slam.pack_images([lefts[s][k] for s in range(B)], [rights[s][k] for s in range(B)],
                                [float(ts[k])] * B) for k in range(n_frames)]
     marks = {}
@@ -274,6 +277,7 @@ def main():
     if args.single:
         one = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1, device.index)
         one.enable_timing(True)
+        one.set_exact_pinv(args.exact)
         sia_ms, n_grad = 0.0, 0
         pk = [one.pack_images([lefts[0][k]], [rights[0][k]], [float(ts[k])]) for k in range(n_frames)]
         for k in range(Wm):

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "svo_oracle.h"
+#include "../include/svo_libm.h"
 
 /* ------------------------------------------------------------------------ */
 /* cv::Rodrigues (vector -> matrix), called from PoseManager::set_pose,
@@ -27,7 +28,11 @@ void svo_o_rodrigues(const float r[3], double R[9])
         R[0] = R[4] = R[8] = 1.0;
         return;
     }
-    double c = cos(theta), s = sin(theta), c1 = 1.0 - c;
+    /* sin / cos from include/svo_libm.h (fdlibm kernels): the reference's libm is not pinned, and
+     * this way the oracle and the device evaluate the same polynomial */
+    double c, s;
+    svo_sincos(theta, &s, &c);
+    const double c1 = 1.0 - c;
     double itheta = 1.0 / theta;
     rx *= itheta; ry *= itheta; rz *= itheta;
     const double rrt[9] = { rx * rx, rx * ry, rx * rz,
@@ -101,7 +106,7 @@ void svo_o_jacobi_svd(float *At, int astep, float *Wout, float *Vt, int vstep,
                 if (fabs(p) <= eps * sqrt((double)a * b)) continue;
 
                 p *= 2;
-                double beta = a - b, gamma = hypot((double)p, beta);
+                double beta = a - b, gamma = svo_hypot((double)p, beta);   /* OpenCV lapack.cpp's own hypot */
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = (float)sqrt(delta / gamma);

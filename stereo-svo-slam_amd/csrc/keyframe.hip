@@ -382,6 +382,13 @@ __global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restri
         kf.flags[i] = f;
         kf.outlier_count[i] = a.kps.outl[i];
         kf.inlier_count[i] = a.kps.inl[i];
+        kf.kf_id[i] = a.kps.kf_id[i];
+        kf.kp_index[i] = a.kps.kp_index[i];
+        kf.score[i] = a.kps.score[i];
+        kf.level_type[i] = a.kps.level_type[i];
+        kf.color[i] = a.kps.color[i];
+        kf.kfx[i] = a.kps.kfx[i];
+        kf.kfP[i] = a.kps.kfP[i];
         not_temp += (f & SVO_IGNORE_TEMPORARY) ? 0 : 1;
     }
     not_temp = wave_sum_i(not_temp);

@@ -4,105 +4,173 @@
 // PoseRefinerCallback::do_calc (:321-348) / get_gradient (:350-412).
 //
 // One persistent workgroup per sequence runs the whole line-search GN on the
-// device: projection and residuals one thread per keypoint, the 21+6
-// normal-equation sums by wavefront shuffles + one LDS pass, the 6x6
-// pseudo-inverse, exponential map and the accept / halve / stop decisions on
-// lane 0 — no host round trip per iteration.
+// device — no host round trip per iteration. The group is ONE wavefront when
+// many sequences share the launch (no barrier anywhere, 256 sequences fit 16
+// CUs) and four wavefronts for a lone sequence.
+//
+// Every float reduction runs in the reference's order: the cost is the
+// sequential sum over the keypoints (:328-341), the 36 + 6 normal-equation
+// sums are sequential `hessian += J^T J`, `err += J^T diff` (:393-395). A
+// lane computes the terms of its keypoints, stages them in LDS in keypoint
+// order, and the accumulators (one lane each) walk that array in order. The
+// stop test of the line search (|dcost| < 1e-4, :273) sits at float rounding
+// of the cost, so any other order changes the accept / halve sequence.
+// Rotation matrices, the 6x6 solve and the accept logic are wave-uniform and
+// computed redundantly by every lane (no broadcast, no barrier).
 #include "svo_kernels.hpp"
-#include "svo_reduce.hpp"
 
 namespace svo {
 
-constexpr int RP_THREADS = 256;
+constexpr int RP_CHUNK = 256;     // keypoints staged per step
 
 struct ReprojShared {
-    PoseMats pm;
-    float red[RP_THREADS / 64][32];
-    float sums[32];
-    float grad[6];
+    float tbuf[2][RP_CHUNK];      // cost terms of a chunk, keypoint order (double buffered)
+    float js[14][RP_CHUNK];       // J (2x6), diff (2) of a chunk
+    float sums[28];
 };
 
-// cost of PoseRefinerCallback::do_calc
-__device__ float reproj_cost(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh) {
-    const int tid = threadIdx.x;
-    __syncthreads();
-    if (tid == 0) pose_mats(pose, sh.pm);
-    __syncthreads();
-    const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
-    float v[1] = {0};
-    for (int i = tid; i < n; i += RP_THREADS) {
-        const uint32_t f = a.flags[i];
-        if (f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY)) continue;
-        const svo_kp2d q = project_point(sh.pm.Rd, sh.pm.t, camd, a.kps3d[i]);
-        const svo_kp2d k = a.kps2d[i];
-        const float d0 = fabsf(q.x - k.x), d1 = fabsf(q.y - k.y);
-        v[0] += d0 + d1;
-    }
-    block_reduce<1, RP_THREADS>(v, sh.red, sh.sums);
-    return sh.sums[0];
+typedef float rp_v4f __attribute__((ext_vector_type(4)));
+
+template <int WAVES>
+__device__ inline void rp_sync() {
+    if constexpr (WAVES > 1) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh) {
+// cost of PoseRefinerCallback::do_calc
+template <int WAVES>
+__device__ float reproj_cost(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh, int& par) {
+    constexpr int T = 64 * WAVES;
     const int tid = threadIdx.x;
-    __syncthreads();
-    if (tid == 0) pose_mats(pose, sh.pm);
-    __syncthreads();
+    PoseMats pm;
+    pose_mats(pose, pm);
+    const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
+    float tot = 0;
+    for (int c0 = 0; c0 < n; c0 += RP_CHUNK) {
+        float* buf = sh.tbuf[par];
+        par ^= 1;
+        for (int j = tid; j < RP_CHUNK; j += T) {
+            const int i = c0 + j;
+            float t = 0;
+            if (i < n) {
+                const uint32_t f = a.flags[i];
+                if (!(f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY))) {
+                    const svo_kp2d q = project_point(pm.Rd, pm.t, camd, a.kps3d[i]);
+                    const svo_kp2d k = a.kps2d[i];
+                    const float d0 = fabsf(q.x - k.x), d1 = fabsf(q.y - k.y);
+                    t = d0 + d1;
+                }
+            }
+            ((SVO_LDS(float)*)buf)[j] = t;       // skipped keypoints add an exact 0
+        }
+        rp_sync<WAVES>();
+        const int m = min(RP_CHUNK, n - c0);
+        const SVO_LDS(rp_v4f)* p = (const SVO_LDS(rp_v4f)*)buf;
+        for (int j = 0; j < (m + 3) >> 2; j++) {  // tot_diff += ... in keypoint order (every lane, same bits)
+            const rp_v4f v = p[j];
+            tot += v.x; tot += v.y; tot += v.z; tot += v.w;
+        }
+    }
+    return tot;
+}
+
+// get_gradient at `pose`: leaves the step in grad[6] (every lane)
+template <int WAVES>
+__device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh, float grad[6]) {
+    constexpr int T = 64 * WAVES;
+    const int tid = threadIdx.x;
+    PoseMats pm;
+    pose_mats(pose, pm);
     const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
     const float fx = a.cam.fx, fy = a.cam.fy;
-    float v[27];
+    // accumulator of this lane: s = js[i0]*js[i2] + js[i1]*js[i3]
+    //   lanes 0..20  H(r,c), r <= c : J[r]*J[c] + J[6+r]*J[6+c]   (:393)
+    //   lanes 21..26 err(r)        : J[r]*d0   + J[6+r]*d1       (:395)
+    int i0 = 0, i1 = 6, i2 = 0, i3 = 6;
+    if (tid < 21) {
+        int r = 0, c = tid;
+        while (c >= 6 - r) { c -= 6 - r; r++; }
+        c += r;
+        i0 = r; i1 = 6 + r; i2 = c; i3 = 6 + c;
+    } else if (tid < 27) {
+        const int r = tid - 21;
+        i0 = r; i1 = 6 + r; i2 = 12; i3 = 13;
+    }
+    float acc = 0;
+    for (int c0 = 0; c0 < n; c0 += RP_CHUNK) {
+        rp_sync<WAVES>();                          // the previous chunk has been consumed
+        for (int j = tid; j < RP_CHUNK; j += T) {
+            const int i = c0 + j;
+            float J[12], d0 = 0, d1 = 0;
 #pragma unroll
-    for (int k = 0; k < 27; k++) v[k] = 0;
-    for (int i = tid; i < n; i += RP_THREADS) {
-        const uint32_t f = a.flags[i];
-        if (f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY)) continue;
-        const svo_kp3d P = a.kps3d[i];
-        const svo_kp2d q = project_point(sh.pm.Rd, sh.pm.t, camd, P);
-        float X[3] = {P.x - sh.pm.t[0], P.y - sh.pm.t[1], P.z - sh.pm.t[2]};
-        mat33f_vec(sh.pm.Ri, X, X);
-        float J[12];
-        pose_jacobian(fx, fy, X[0], X[1], X[2], J);
-        const svo_kp2d k = a.kps2d[i];
-        const float d0 = k.x - q.x, d1 = k.y - q.y;
-        if (((double)fabsf(d0) > 3.0) || ((double)fabsf(d1) > 3.0)) continue;
+            for (int k = 0; k < 12; k++) J[k] = 0;
+            if (i < n) {
+                const uint32_t f = a.flags[i];
+                if (!(f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY))) {
+                    const svo_kp3d P = a.kps3d[i];
+                    const svo_kp2d q = project_point(pm.Rd, pm.t, camd, P);
+                    float X[3] = {P.x - pm.t[0], P.y - pm.t[1], P.z - pm.t[2]};
+                    mat33f_vec(pm.Ri, X, X);
+                    const svo_kp2d k = a.kps2d[i];
+                    const float e0 = k.x - q.x, e1 = k.y - q.y;
+                    if (!(((double)fabsf(e0) > 3.0) || ((double)fabsf(e1) > 3.0))) {
+                        pose_jacobian(fx, fy, X[0], X[1], X[2], J);
+                        d0 = e0; d1 = e1;
+                    }
+                }
+            }
+            // a keypoint that does not take part stages zeros: 0*0 + 0*0 added to a sum changes nothing
+#pragma unroll
+            for (int k = 0; k < 12; k++) ((SVO_LDS(float)*)sh.js[k])[j] = J[k];
+            ((SVO_LDS(float)*)sh.js[12])[j] = d0;
+            ((SVO_LDS(float)*)sh.js[13])[j] = d1;
+        }
+        rp_sync<WAVES>();
+        if (tid < 27) {
+            const int m = min(RP_CHUNK, n - c0);
+            const SVO_LDS(rp_v4f)* p0 = (const SVO_LDS(rp_v4f)*)sh.js[i0];
+            const SVO_LDS(rp_v4f)* p1 = (const SVO_LDS(rp_v4f)*)sh.js[i1];
+            const SVO_LDS(rp_v4f)* p2 = (const SVO_LDS(rp_v4f)*)sh.js[i2];
+            const SVO_LDS(rp_v4f)* p3 = (const SVO_LDS(rp_v4f)*)sh.js[i3];
+            for (int j = 0; j < (m + 3) >> 2; j++) {
+                const rp_v4f x0 = p0[j], x1 = p1[j], x2 = p2[j], x3 = p3[j];
+                { float s = 0; s += x0.x * x2.x; s += x1.x * x3.x; acc += s; }
+                { float s = 0; s += x0.y * x2.y; s += x1.y * x3.y; acc += s; }
+                { float s = 0; s += x0.z * x2.z; s += x1.z * x3.z; acc += s; }
+                { float s = 0; s += x0.w * x2.w; s += x1.w * x3.w; acc += s; }
+            }
+        }
+    }
+    rp_sync<WAVES>();
+    if (tid < 27) ((SVO_LDS(float)*)sh.sums)[tid] = acc;
+    rp_sync<WAVES>();
+    float H[36], e[6], twist[6];
+    {
         int idx = 0;
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
             for (int c = r; c < 6; c++) {
-                float s = 0;
-                s += J[r] * J[c];
-                s += J[6 + r] * J[6 + c];
-                v[idx++] += s;
+                const float v = ((const SVO_LDS(float)*)sh.sums)[idx++];
+                H[r * 6 + c] = v; H[c * 6 + r] = v;   // J[r]*J[c] == J[c]*J[r]: the lower triangle has the same bits
             }
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            float s = 0;
-            s += J[r] * d0;
-            s += J[6 + r] * d1;
-            v[21 + r] += s;
-        }
+        for (int r = 0; r < 6; r++) e[r] = ((const SVO_LDS(float)*)sh.sums)[21 + r];
     }
-    block_reduce<27, RP_THREADS>(v, sh.red, sh.sums);
-    if (tid == 0) {
-        float H[36], e[6], twist[6];
-        int idx = 0;
-        for (int r = 0; r < 6; r++)
-            for (int c = r; c < 6; c++) { H[r * 6 + c] = sh.sums[idx]; H[c * 6 + r] = sh.sums[idx]; idx++; }
-        for (int r = 0; r < 6; r++) e[r] = sh.sums[21 + r];
-        gn_solve6(H, e, twist, a.exact_pinv != 0);
-        exponential_map(twist, sh.grad);   // not rotated (pose_refinement.cpp:398-411)
-    }
-    __syncthreads();
+    gn_solve6(H, e, twist, a.exact_pinv != 0);
+    exponential_map(twist, grad);                  // not rotated (pose_refinement.cpp:398-411)
 }
 
-__global__ __launch_bounds__(RP_THREADS) void reproj_gn_kernel(const ReprojArgs* __restrict__ args) {
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs* __restrict__ args) {
+    constexpr int T = 64 * WAVES;
     const ReprojArgs& a = args[blockIdx.x];
     const int n = *a.n_ptr;
     const int tid = threadIdx.x;
     __shared__ ReprojShared sh;
 
     if (a.tracked) {   // merge, pose_refinement.cpp:125-150
-        for (int i = tid; i < n; i += RP_THREADS) {
+        for (int i = tid; i < n; i += T) {
             const svo_kp2d k = a.kps2d[i], t = a.tracked[i];
             const float dx = k.x - t.x, dy = k.y - t.y;
             const float diff = dx * dx + dy * dy;
@@ -116,23 +184,25 @@ __global__ __launch_bounds__(RP_THREADS) void reproj_gn_kernel(const ReprojArgs*
     }
 
     float x0[6];
+#pragma unroll
     for (int j = 0; j < 6; j++) x0[j] = a.pose_in[j];
     const int maxIter = 50;
-    int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0;
-    float prev_cost = reproj_cost(a, n, x0, sh);
+    int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0, par = 0;
+    float prev_cost = reproj_cost<WAVES>(a, n, x0, sh, par);
     const float initial = prev_cost;
     for (int i = 0; i < maxIter; i++) {
-        reproj_gradient(a, n, x0, sh);
-        n_grad++;
         float g[6];
-        for (int j = 0; j < 6; j++) g[j] = sh.grad[j];
+        reproj_gradient<WAVES>(a, n, x0, sh, g);
+        n_grad++;
         float k = 1.0f;
         for (; i < maxIter; i++) {
             float x[6];
+#pragma unroll
             for (int j = 0; j < 6; j++) x[j] = x0[j] + k * g[j];
-            const float new_cost = reproj_cost(a, n, x, sh);
+            const float new_cost = reproj_cost<WAVES>(a, n, x, sh, par);
             n_cost++;
             if (new_cost < prev_cost) {
+#pragma unroll
                 for (int j = 0; j < 6; j++) x0[j] = x[j];
                 prev_cost = new_cost;
                 accepted++;
@@ -159,7 +229,10 @@ __global__ __launch_bounds__(RP_THREADS) void reproj_gn_kernel(const ReprojArgs*
 }
 
 void launch_reproj(const ReprojArgs* d_args, int batch, hipStream_t stream) {
-    hipLaunchKernelGGL(reproj_gn_kernel, dim3(batch), dim3(RP_THREADS), 0, stream, d_args);
+    if (batch >= 16)
+        hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), 0, stream, d_args);
+    else
+        hipLaunchKernelGGL(reproj_gn_kernel<4>, dim3(batch), dim3(256), 0, stream, d_args);
 }
 
 }  // namespace svo

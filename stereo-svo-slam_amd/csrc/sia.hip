@@ -7,579 +7,645 @@
 // ONE persistent workgroup per sequence runs every pyramid level and every
 // Gauss-Newton / line-search iteration on the device (the reference makes up
 // to 50 cost evaluations per level; a launch per evaluation would cost more
-// than the whole CPU frame). Per level:
-//   * both level images (previous and current frame; 23x15 .. 188x120 bytes at
-//     752x480) are staged into LDS, so every 4x4 / 3x3 tap is a ds_read;
-//   * everything that depends only on the previous frame — image gradients,
-//     reference patch sums, the reference half of the cost — is computed once
-//     into per-patch-pixel records (LDS when they fit, else a workspace in HBM);
-//   * a cost evaluation = Rodrigues on lane 0 -> projection in double, one
-//     thread per keypoint -> 16 lanes per keypoint patch -> DPP row/wave
-//     reduction + one LDS pass;
-//   * get_gradient always follows a cost evaluation of the same pose, so it
-//     reuses that rotation and projection; the 21+6 normal-equation sums are
-//     built per keypoint as J^T (sum_px g g^T) J (the reference never caches
-//     its Hessian: the member is shadowed, pose_estimator.cpp:399 vs :61),
-//     reduced over the workgroup and solved on lane 0.
+// than the whole CPU frame). The shape of the workgroup is chosen per launch:
+//
+//   sia_gn_kernel<WAVES, KPL>: 64*WAVES lanes, every lane owns KPL keypoints.
+//
+//   * A lane keeps everything about its keypoints that depends only on the
+//     previous frame in REGISTERS for the whole level: per patch pixel the
+//     reference half of the cost, the reference patch sum and the image
+//     gradient (64 floats per keypoint), plus sum g g^T. Nothing per-pixel is
+//     ever in LDS or HBM.
+//   * The current level image (23x15 .. 188x120 bytes at 752x480) is staged in
+//     LDS once per level; a cost evaluation reads the 5x5 window of its patch,
+//     a gradient evaluation the 6x6 window, as ds_read_u8.
+//   * Everything that is the same for all keypoints — Rodrigues, the 6x6
+//     solve, the exponential map, the accept / halve / stop logic — is
+//     computed redundantly by every lane: no broadcast, no barrier. With
+//     WAVES == 1 (the batch configuration: one wavefront per sequence, ~25 KB
+//     of LDS, several sequences per CU) the kernel has no barrier at all; with
+//     more waves there is one per evaluation.
+//   * Float reductions follow the reference's order. The cost is summed per
+//     keypoint over its 16 pixels in the lane (image_comparison.cpp:67-88) and
+//     then over the keypoints in index order by every lane from an LDS array
+//     (:112-117): the stop test |dcost| < 1 is exact. The normal equations
+//     have two forms: the default builds sum_kp J^T (sum_px g g^T) J with a
+//     wave reduction and solves by LDL^T; `exact` (svo_*_set_exact_pinv)
+//     accumulates hessian += row^T row and residual -= row * diff row by row in
+//     storage order (:399-403, :472-477) — one lane per accumulator walking a
+//     staged array — and inverts by the Jacobi SVD, so the whole iteration
+//     trace is the reference's.
 #include "svo_kernels.hpp"
 #include <atomic>
 #include <algorithm>
-#include "svo_reduce.hpp"
 
 namespace svo {
 
-#ifndef SVO_SIA_THREADS
-#define SVO_SIA_THREADS 512
-#endif
-constexpr int SIA_THREADS = SVO_SIA_THREADS;
-constexpr int SIA_WAVES = SIA_THREADS / 64;
-constexpr size_t SIA_LDS_BUDGET = 140 * 1024;
-
-struct SiaShared {
-    PoseMats pm;
-    float red[SIA_WAVES][28];
-    float sums[28];
-    float grad[6];
-#ifdef SVO_SIA_STAMPS
-    long long stamp[12];   // diagnostic build only: cycles per phase, summed by thread 0
-#endif
-};
-
-#ifdef SVO_SIA_STAMPS
-#define SIA_STAMP(t) const long long t = __builtin_readcyclecounter()
-#define SIA_ACC(i, t1, t0) do { if (threadIdx.x == 0) sh.stamp[i] += (t1) - (t0); } while (0)
-#else
-#define SIA_STAMP(t)
-#define SIA_ACC(i, t1, t0)
-#endif
-
-// position of patch pixel (r, c) exactly as the reference's nested loops reach
-// it: x++ per column, x -= 4 and y++ at the end of a row (float arithmetic).
-__device__ inline void patch_pos(float x0, float y0, int r, int c, float& x, float& y) {
-    x = x0; y = y0;
-    for (int rr = 0; rr < r; rr++) {
-        x += 1.f; x += 1.f; x += 1.f; x += 1.f;
-        x -= 4.f;
-        y += 1.f;
-    }
-    for (int cc = 0; cc < c; cc++) x += 1.f;
-}
+constexpr size_t SIA_LDS_BUDGET = 156 * 1024;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 
-// one level image: the LDS copy (LDS == true, row stride = w) or the HBM original
-template <bool LDS>
+#define LDSF(p) ((SVO_LDS(float)*)(p))
+#define LDSCF(p) ((const SVO_LDS(float)*)(p))
+
+// the current level image in LDS (rows padded to a dword)
 struct LevelImg {
-    const uint8_t* p;
+    const uint8_t* p;       // LDS
     int w, h, stride;
-    __device__ inline int at(int y, int x) const { return (int)mem_ld<LDS>(p, y * stride + x); }
+    __device__ inline float at(int o) const { return (float)((const SVO_LDS(uint8_t)*)p)[o]; }
 };
 
-// get_patch_sum, src/lib/pose_estimator.cpp:82-112
-template <bool LDS>
-__device__ inline float patch_sum_img(const LevelImg<LDS>& im, float cx, float cy) {
+// get_patch_sum, src/lib/pose_estimator.cpp:82-112, on the LDS image
+__device__ inline float patch_sum_lds(const LevelImg& im, float cx, float cy) {
     const float sx = cx - 0.5f, sy = cy - 0.5f;
     const int ipx = (int)floorf(sx), ipy = (int)floorf(sy);
     const float x2 = sx - (float)ipx, y2 = sy - (float)ipy;
     const float x1 = 1.0f - x2, y1 = 1.0f - y2;
     const int o = ipy * im.stride + ipx;
-    const float a00 = (float)mem_ld<LDS>(im.p, o), a01 = (float)mem_ld<LDS>(im.p, o + 1),
-                a02 = (float)mem_ld<LDS>(im.p, o + 2);
-    const float a10 = (float)mem_ld<LDS>(im.p, o + im.stride), a11 = (float)mem_ld<LDS>(im.p, o + im.stride + 1),
-                a12 = (float)mem_ld<LDS>(im.p, o + im.stride + 2);
-    const float a20 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride), a21 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride + 1),
-                a22 = (float)mem_ld<LDS>(im.p, o + 2 * im.stride + 2);
+    const float a00 = im.at(o), a01 = im.at(o + 1), a02 = im.at(o + 2);
+    const float a10 = im.at(o + im.stride), a11 = im.at(o + im.stride + 1), a12 = im.at(o + im.stride + 2);
+    const float a20 = im.at(o + 2 * im.stride), a21 = im.at(o + 2 * im.stride + 1),
+                a22 = im.at(o + 2 * im.stride + 2);
     const float intensity = x1 * y1 * a00 + y1 * a01 + x2 * y1 * a02 +
                             x1 * a10 + a11 + x2 * a12 +
                             x1 * y2 * a20 + y2 * a21 + x2 * y2 * a22;
     return intensity;
 }
 
-// per-level working set of the workgroup. LDS == true: images, records and the
-// per-keypoint arrays are in LDS; false: they stay in HBM (large configurations).
-template <bool LDS>
-struct LevelCtx {
-    LevelImg<LDS> cur;      // sampled by every iteration: LDS copy when the working set is in LDS
-    LevelImg<false> prev;   // read once per level (reference patches): stays in HBM / L2
-    float fx, fy, cx, cy;
-    int patch;              // window_size_pose_estimator
-    // per patch pixel (n*16): reference cost sample, gradients, reference patch sum
-    float* rec_i1; float* rec_g0; float* rec_g1; float* rec_ps;
-    // per keypoint: point + active flag, sum g g^T
-    v4f* kp_pt; v4f* kp_G;
-    v2f* proj;              // projection at the pose of the last evaluation (always LDS)
-    v4f* kp_cw;             // bilinear weights of the cost patch at that projection
-    int* kp_cb;             // byte offset of its first tap in the current level image, < 0: outside
-    float* kp_J;            // [n][12] Jacobian of the last evaluated pose (gradient only)
-    float* kp_rows;         // [n][8]  x and y of the four patch rows as the reference's loops reach them
-};
-
-__device__ inline float block_sum1(float v, SiaShared& sh) {
-    v = wave_sum_dpp(v);
-    const int tid = threadIdx.x;
-    if ((tid & 63) == 0) sh.red[tid >> 6][0] = v;
-    __syncthreads();
-    float s = sh.red[0][0];
-#pragma unroll
-    for (int w = 1; w < SIA_WAVES; w++) s += sh.red[w][0];
-    return s;   // same order in every thread
+// sequential sum of buf[0..n) (LDS, zero padded to a multiple of 4) continuing from s
+__device__ inline float ordered_sum(const float* buf, int n, float s) {
+    const SVO_LDS(v4f)* p = (const SVO_LDS(v4f)*)buf;
+    for (int j = 0; j < (n + 3) >> 2; j++) {
+        const v4f v = p[j];
+        s += v.x; s += v.y; s += v.z; s += v.w;
+    }
+    return s;
 }
 
-// do_calc: project + get_total_intensity_diff. Phase B (one thread per keypoint)
-// projects and derives the bilinear weights / first tap of the 4x4 cost patch;
-// phase C (one thread per patch pixel) is 1 record read, 4 taps and 8 flops.
-template <bool LDS>
-__device__ float sia_cost(const SiaArgs& a, int n, const LevelCtx<LDS>& L, const float pose[6], SiaShared& sh) {
-    const int tid = threadIdx.x;
-    SIA_STAMP(c0);
-    __syncthreads();                      // previous readers of pm / proj / red are done
-    SIA_STAMP(c1);
-    if (tid == 0) pose_mats(pose, sh.pm);
-    SIA_STAMP(c2);
-    __syncthreads();
-    const CamD camd = make_camd(L.fx, L.fy, L.cx, L.cy, a.cam);
-    const int ps = L.patch;
-    const float half_size = ((float)ps - 1.0f) / 2.0f;
-    for (int i = tid; i < n; i += SIA_THREADS) {
-        const v4f p = mem_ld<LDS>(L.kp_pt, i);
-        int cb = -1;
-        v4f cw = {0, 0, 0, 0};
-        if (p.w != 0.f) {
-            const svo_kp2d q = project_point(sh.pm.Rd, sh.pm.t, camd, svo_kp3d{p.x, p.y, p.z});
-            mem_st<LDS>(L.proj, i, v2f{q.x, q.y});
-            const float s2x = q.x - half_size, s2y = q.y - half_size;
-            const float f2x = floorf(s2x), f2y = floorf(s2y);
-            // (absurd projections are kept out of the int conversion)
-            if (f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f) {
-                const int ip2x = (int)f2x, ip2y = (int)f2y;
-                if (ip2y + ps < L.cur.h && ip2x + ps < L.cur.w) {
-                    const float x22 = s2x - (float)ip2x, y22 = s2y - (float)ip2y;
-                    const float x21 = 1.0f - x22, y21 = 1.0f - y22;
-                    cw = v4f{x21 * y21, x22 * y21, x21 * y22, x22 * y22};
-                    cb = ip2y * L.cur.stride + ip2x;
-                }
-            }
-        }
-        mem_st<LDS>(L.kp_cw, i, cw);
-        mem_st<LDS>(L.kp_cb, i, cb);
-    }
-    SIA_STAMP(c3);
-    __syncthreads();
-    SIA_STAMP(c4);
-    float v = 0;
-    for (int idx = tid; idx < n * 16; idx += SIA_THREADS) {
-        const int kp = idx >> 4, px = idx & 15;
-        const float i1 = mem_ld<LDS>(L.rec_i1, idx);
-        const int cb = mem_ld<LDS>(L.kp_cb, kp);
-        if (i1 != i1 || cb < 0) continue;            // reference or current half outside / inactive
-        const v4f m = mem_ld<LDS>(L.kp_cw, kp);
-        const int o = cb + (px >> 2) * L.cur.stride + (px & 3);
-        float i2 = 0;
-        i2 += m.x * (float)mem_ld<LDS>(L.cur.p, o);
-        i2 += m.y * (float)mem_ld<LDS>(L.cur.p, o + 1);
-        i2 += m.z * (float)mem_ld<LDS>(L.cur.p, o + L.cur.stride);
-        i2 += m.w * (float)mem_ld<LDS>(L.cur.p, o + L.cur.stride + 1);
-        v += fabsf(i1 - i2);
-    }
-    SIA_STAMP(c5);
-    const float total = block_sum1(v, sh);
-    SIA_STAMP(c6);
-    SIA_ACC(0, c1, c0); SIA_ACC(1, c2, c1); SIA_ACC(2, c3, c2); SIA_ACC(3, c4, c3);
-    SIA_ACC(4, c5, c4); SIA_ACC(5, c6, c5); SIA_ACC(6, 1, 0);
-    return total;
+// Dynamic LDS of one workgroup (byte offsets). cap = keypoint capacity (multiple of 64),
+// T = threads. Per keypoint: 9 floats (point, last projection, sum g g^T, active) and the
+// 64 per-pixel records, all struct-of-arrays with the keypoint index fastest (conflict free).
+enum { KF_PX = 0, KF_PY, KF_PZ, KF_QX, KF_QY, KF_GXX, KF_GXY, KF_GYY, KF_ACT, KF_COUNT };
+enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
+struct SiaLds {
+    size_t img, tbuf, kpf, rec, sums, stage, total;
+};
+__host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact) {
+    SiaLds l;
+    size_t off = 0;
+    l.img = off;   off += ((size_t)img_bytes + 15) & ~(size_t)15;
+    l.tbuf = off;  off += (size_t)2 * cap * 4;
+    l.kpf = off;   off += (size_t)KF_COUNT * cap * 4;
+    l.rec = off;   off += (size_t)64 * cap * 4;
+    l.sums = off;  off += 16 * 32 * 4;                                 // [WAVES <= 16][32]
+    l.stage = off; off += exact ? (size_t)7 * (64 * 16 + 4) * 4 : 0;  // 7 planes of one wave's rows, padded: distinct banks per plane
+    l.total = off;
+    return l;
+}
+
+template <int WAVES>
+__device__ inline void sia_sync() {
+    if constexpr (WAVES > 1) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
 }
 
 // (r, c) of the 21 upper-triangle entries of H in the order they are stored
 __constant__ int8_t c_tri_r[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 __constant__ int8_t c_tri_c[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 
-// get_gradient (with calculate_hessian) at the pose of the LAST cost evaluation
-// (rotation in sh.pm and projections in L.proj are reused); leaves the step in sh.grad.
-// Phase B' (one thread per keypoint): Jacobian and the four row starts of the
-// residual patch. Phase C' (one thread per patch pixel): residual * gradient,
-// summed over the 16 lanes of the patch (one DPP row); then every lane owns two
-// of the 27 outputs (21 entries of J^T G J, 6 of -J^T s).
-template <bool LDS>
-__device__ void sia_gradient(const SiaArgs& a, int n, const LevelCtx<LDS>& L, SiaShared& sh, float* dbg) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    SIA_STAMP(g0);
-    for (int i = tid; i < n; i += SIA_THREADS) {
-        const v4f pt = mem_ld<LDS>(L.kp_pt, i);
-        float J[12];
-        float rows[8];
-        if (pt.w != 0.f) {
-            float X[3] = {pt.x - sh.pm.t[0], pt.y - sh.pm.t[1], pt.z - sh.pm.t[2]};
-            mat33f_vec(sh.pm.Ri, X, X);
-            pose_jacobian(L.fx, L.fy, X[0], X[1], X[2], J);
-            const v2f q = mem_ld<LDS>(L.proj, i);
-            float x = q.x - 2.f, y = q.y - 2.f;      // x++ per column, x -= 4 and y++ per row
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                rows[r] = x; rows[4 + r] = y;
-                x += 1.f; x += 1.f; x += 1.f; x += 1.f;
-                x -= 4.f;
-                y += 1.f;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; k++) J[k] = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) rows[k] = 0;
+// ---------------------------------------------------------------- records
+// Everything the alignment needs from the PREVIOUS frame is independent of the pose: per patch
+// pixel the reference half of the cost (image_comparison.cpp:20-88), the reference patch sum of
+// the residual (:449-460) and the image gradient of calculate_hessian (:351-388), per keypoint
+// sum g g^T. sia_prep_kernel computes them for every level in one launch, one lane per
+// (keypoint, patch pixel), into a struct-of-arrays workspace: rec_ws[level - min][row][rec_cap]
+// with row = field * 16 + pixel (fields REC_*), rows 64..66 = sum gxgx, gxgy, gygy.
+constexpr int SIA_REC_ROWS = 68;
+
+__global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict__ args) {
+    const SiaArgs& a = args[blockIdx.z];
+    const int n = min(*a.n_ptr, a.rec_cap);
+    const int level = a.cam.min_pyramid_level_pose_estimation + blockIdx.y;
+    if (level >= a.cam.max_pyramid_levels) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int kp = idx >> 4, px = idx & 15;
+    const int span = (n + 3) & ~3;                       // the consumer copies float4 columns
+    if (kp >= span) return;                              // (whole 16-lane rows leave together)
+    const ImgView prev = a.prev[level];
+    const int divider = 1 << level;
+    float g0 = 0, g1 = 0, psr = __builtin_nanf(""), i1 = __builtin_nanf("");
+    const bool active = kp < n && !(a.flags && (a.flags[kp] & SVO_IGNORE_TEMPORARY));
+    if (active) {
+        svo_kp2d kref = a.kps2d[kp];
+        if (level != 0) { kref.x /= divider; kref.y /= divider; }      // setLevel
+        // the reference's walk over the patch: x++ per column, x -= 4 and y++ per row (float arithmetic)
+        float kx = kref.x - 2.f, ky = kref.y - 2.f;
+        for (int rr = 0; rr < (px >> 2); rr++) {
+            kx += 1.f; kx += 1.f; kx += 1.f; kx += 1.f;
+            kx -= 4.f;
+            ky += 1.f;
         }
-#pragma unroll
-        for (int k = 0; k < 12; k++) mem_st<LDS>(L.kp_J, i * 12 + k, J[k]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) mem_st<LDS>(L.kp_rows, i * 8 + k, rows[k]);
-    }
-    __syncthreads();
-    float acc_a = 0, acc_b = 0;                      // outputs px and px + 16
-    const int px = tid & 15;
-    const int oa = px, ob = px + 16;
-    const int ra = c_tri_r[oa], ca = c_tri_c[oa];
-    const int rb = ob < 21 ? c_tri_r[ob] : ob - 21, cb = ob < 21 ? c_tri_c[ob] : 0;
-    const int npad = (n * 16 + 63) & ~63;            // whole waves take part in the row sums
-    for (int idx = tid; idx < npad; idx += SIA_THREADS) {
-        const int kp = idx >> 4;
-        float s0 = 0, s1 = 0;
-        const bool in = idx < n * 16;
-        if (in) {
-            const float psr = mem_ld<LDS>(L.rec_ps, idx);
-            if (psr == psr) {                        // active and reference pixel inside (:449-451)
-                const int r = px >> 2, c = px & 3;
-                float kx = mem_ld<LDS>(L.kp_rows, kp * 8 + r);
-                const float ky = mem_ld<LDS>(L.kp_rows, kp * 8 + 4 + r);
-                kx += (c > 0) ? 1.f : 0.f;           // x++ per column (adding 0 is exact)
-                kx += (c > 1) ? 1.f : 0.f;
-                kx += (c > 2) ? 1.f : 0.f;
-                if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
-                      ((double)kx + 2.0) > L.cur.w || ((double)ky + 2.0) > L.cur.h)) {
-                    const float d = patch_sum_img(L.cur, kx, ky) - psr;
-                    s0 = mem_ld<LDS>(L.rec_g0, idx) * d;
-                    s1 = mem_ld<LDS>(L.rec_g1, idx) * d;
-                }
-            }
+        for (int cc = 0; cc < (px & 3); cc++) kx += 1.f;
+        // calculate_hessian bounds (:351-352)
+        if (!(((double)kx - 2.0) < 0 || ((double)ky - 2.0) < 0 ||
+              ((double)kx + 3.0) >= prev.w || ((double)ky + 3.0) >= prev.h)) {
+            const float int1 = patch_sum(prev.data, prev.stride, kx + 1, ky);
+            const float int2 = patch_sum(prev.data, prev.stride, kx - 1, ky);
+            const float int3 = patch_sum(prev.data, prev.stride, kx, ky + 1);
+            const float int4 = patch_sum(prev.data, prev.stride, kx, ky - 1);
+            g0 = int1 - int2; g1 = int3 - int4;
         }
-        s0 = row16_sum_dpp(s0);
-        s1 = row16_sum_dpp(s1);
-        if (in) {
-            const float* Jk = L.kp_J + kp * 12;
-            const v4f G = mem_ld<LDS>(L.kp_G, kp);
-            {   // H entry (ra, ca) = J_r^T (G J)_c
-                const float j0c = mem_ld<LDS>(Jk, ca), j1c = mem_ld<LDS>(Jk, 6 + ca);
-                const float m0 = G.x * j0c + G.y * j1c, m1 = G.y * j0c + G.z * j1c;
-                acc_a += mem_ld<LDS>(Jk, ra) * m0 + mem_ld<LDS>(Jk, 6 + ra) * m1;
-            }
-            if (ob < 21) {
-                const float j0c = mem_ld<LDS>(Jk, cb), j1c = mem_ld<LDS>(Jk, 6 + cb);
-                const float m0 = G.x * j0c + G.y * j1c, m1 = G.y * j0c + G.z * j1c;
-                acc_b += mem_ld<LDS>(Jk, rb) * m0 + mem_ld<LDS>(Jk, 6 + rb) * m1;
-            } else if (ob < 27) {
-                acc_b -= mem_ld<LDS>(Jk, rb) * s0 + mem_ld<LDS>(Jk, 6 + rb) * s1;
+        // reference half of the residual test (:449-453)
+        if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
+              ((double)kx + 2.0) > prev.w || ((double)ky + 2.0) > prev.h))
+            psr = patch_sum(prev.data, prev.stride, kx, ky);
+        // reference half of the cost (image_comparison.cpp:20-88): one window test per keypoint
+        const int ps = a.cam.window_size_pose_estimator;
+        const float half_size = ((float)ps - 1.0f) / 2.0f;
+        const float s1x = kref.x - half_size, s1y = kref.y - half_size;
+        const float f1x = floorf(s1x), f1y = floorf(s1y);
+        if (f1x >= 0.f && f1y >= 0.f && f1x < 65536.f && f1y < 65536.f) {
+            const int ip1x = (int)f1x, ip1y = (int)f1y;
+            if (ip1y + ps < prev.h && ip1x + ps < prev.w) {
+                const float x12 = s1x - (float)ip1x, y12 = s1y - (float)ip1y;
+                const float x11 = 1.0f - x12, y11 = 1.0f - y12;
+                const float m0 = x11 * y11, m1 = x12 * y11, m2 = x11 * y12, m3 = x12 * y12;
+                const uint8_t* p = prev.data + (size_t)((px >> 2) + ip1y) * prev.stride + (px & 3) + ip1x;
+                float t = 0;
+                t += m0 * (float)p[0];
+                t += m1 * (float)p[1];
+                t += m2 * (float)p[prev.stride];
+                t += m3 * (float)p[prev.stride + 1];
+                i1 = t;
             }
         }
     }
-    // the four patches of a wave, then the waves
-    acc_a += __shfl_xor(acc_a, 16, 64); acc_a += __shfl_xor(acc_a, 32, 64);
-    acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
-    if (lane < 16) {
-        sh.red[wave][oa] = acc_a;
-        if (ob < 27) sh.red[wave][ob] = acc_b;
+    float* out = a.rec_ws + (size_t)blockIdx.y * SIA_REC_ROWS * a.rec_cap;
+    out[(size_t)(REC_I1 * 16 + px) * a.rec_cap + kp] = i1;
+    out[(size_t)(REC_PS * 16 + px) * a.rec_cap + kp] = psr;
+    out[(size_t)(REC_G0 * 16 + px) * a.rec_cap + kp] = g0;
+    out[(size_t)(REC_G1 * 16 + px) * a.rec_cap + kp] = g1;
+    const float gxx = row16_sum_dpp(g0 * g0), gxy = row16_sum_dpp(g0 * g1), gyy = row16_sum_dpp(g1 * g1);
+    if (px == 0) {
+        out[(size_t)64 * a.rec_cap + kp] = gxx;
+        out[(size_t)65 * a.rec_cap + kp] = gxy;
+        out[(size_t)66 * a.rec_cap + kp] = gyy;
     }
-    __syncthreads();
-    if (tid < 27) {
-        float s = sh.red[0][tid];
-#pragma unroll
-        for (int w = 1; w < SIA_WAVES; w++) s += sh.red[w][tid];
-        sh.sums[tid] = s;
-    }
-    __syncthreads();
-    SIA_STAMP(g1);
-    SIA_ACC(7, g1, g0);
-    if (tid == 0) {
-        float H[36], b[6], delta[6], pg[6];
-        int q = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = r; c < 6; c++) { H[r * 6 + c] = sh.sums[q]; H[c * 6 + r] = sh.sums[q]; q++; }
-#pragma unroll
-        for (int r = 0; r < 6; r++) b[r] = sh.sums[21 + r];
-        gn_solve6(H, b, delta, a.exact_pinv != 0);
-        exponential_map(delta, pg);
-        mat33f_vec(sh.pm.R, pg, sh.grad);            // pose_estimator.cpp:495-497
-        mat33f_vec(sh.pm.R, pg + 3, sh.grad + 3);
-        if (dbg) {
-            for (int k = 0; k < 36; k++) dbg[k] = H[k];
-            for (int k = 0; k < 6; k++) { dbg[36 + k] = b[k]; dbg[42 + k] = sh.grad[k]; }
-        }
-    }
-    SIA_STAMP(g2);
-    SIA_ACC(8, g2, g1); SIA_ACC(9, 1, 0);
-    __syncthreads();
 }
 
-// Working set of one sequence, sized by the number of keypoints n:
-//   per keypoint 128 B : projection, cost weights + offset, Jacobian, row starts,
-//                        point + active flag, sum g g^T
-//   per patch pixel 16 B (256 B per keypoint): the per-level records
-//   2 x the largest level image the estimator uses
-// It lives in LDS when it fits the budget (n <= ~250 at 752x480), else in the
-// HBM workspace (SiaArgs::kp_ws / cache). Host and device share this function.
-struct SiaLds {
-    size_t proj, kp_cw, kp_cb, kp_J, kp_rows, kp_pt, kp_G, img_cur, rec, total;
-    int img_bytes;
-};
+// diagnostic build (-DSVO_SIA_STAMPS, tools/sia_stamps.py): cycles per phase, written to dbg_H
+#ifdef SVO_SIA_STAMPS
+#define SIA_T(v) const long long v = __builtin_readcyclecounter()
+#define SIA_ADD(i, t1, t0) st[i] += (t1) - (t0)
+#else
+#define SIA_T(v)
+#define SIA_ADD(i, t1, t0)
+#endif
 
-__host__ __device__ inline SiaLds sia_lds_layout(int n, int max_img_bytes) {
-    SiaLds l;
-    const size_t np = ((size_t)n + 15) & ~(size_t)15;
-    size_t off = 0;
-    l.proj = off;    off += np * 8;
-    l.kp_cb = off;   off += np * 4;
-    l.kp_cw = off;   off += np * 16;
-    l.kp_J = off;    off += np * 48;
-    l.kp_rows = off; off += np * 32;
-    l.kp_pt = off;   off += np * 16;
-    l.kp_G = off;    off += np * 16;
-    const size_t img = ((size_t)max_img_bytes + 15) & ~(size_t)15;
-    l.img_bytes = (int)img;
-    l.img_cur = off; off += img;
-    l.rec = off;     off += np * 256;
-    l.total = off;
-    return l;
-}
+template <int WAVES>
+struct Sia {
+    static constexpr int T = 64 * WAVES;
+#ifdef SVO_SIA_STAMPS
+    long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
-template <bool LDS>
-__device__ void sia_run(const SiaArgs& a, int n, SiaShared& sh, uint8_t* dyn, const SiaLds& lay) {
-    const int tid = threadIdx.x;
-    LevelCtx<LDS> L;
-    {
-        // LDS: the dynamic segment; HBM: kp_ws (cap * 40 floats) and cache (cap * 16 float4)
-        uint8_t* base = LDS ? dyn : reinterpret_cast<uint8_t*>(a.kp_ws);
-        const SiaLds g = LDS ? lay : sia_lds_layout(a.cap, 0);
-        L.proj = reinterpret_cast<v2f*>(base + g.proj);
-        L.kp_cw = reinterpret_cast<v4f*>(base + g.kp_cw);
-        L.kp_cb = reinterpret_cast<int*>(base + g.kp_cb);
-        L.kp_J = reinterpret_cast<float*>(base + g.kp_J);
-        L.kp_rows = reinterpret_cast<float*>(base + g.kp_rows);
-        L.kp_pt = reinterpret_cast<v4f*>(base + g.kp_pt);
-        L.kp_G = reinterpret_cast<v4f*>(base + g.kp_G);
-        float* r = LDS ? reinterpret_cast<float*>(dyn + lay.rec) : reinterpret_cast<float*>(a.cache);
-        const size_t c16 = LDS ? (size_t)(((size_t)n + 15) & ~(size_t)15) * 16 : (size_t)a.cap * 16;
-        L.rec_i1 = r; L.rec_g0 = r + c16; L.rec_g1 = r + 2 * c16; L.rec_ps = r + 3 * c16;
-    }
-    L.patch = a.cam.window_size_pose_estimator;
+    const SiaArgs& a;
+    int n, cap;
+    uint8_t* dyn;
+    SiaLds lay;
+    LevelImg cur;
+    float fx, fy, cx, cy;
+    int patch;
+    int par = 0;
 
-    // active set and points (PoseEstimatorCallback ctor, :238-245)
-    for (int i = tid; i < n; i += SIA_THREADS) {
-        const svo_kp3d P = a.kps3d[i];
-        const bool active = !(a.flags && (a.flags[i] & SVO_IGNORE_TEMPORARY));
-        mem_st<LDS>(L.kp_pt, i, v4f{P.x, P.y, P.z, active ? 1.f : 0.f});
-    }
+    __device__ Sia(const SiaArgs& a_, int n_, int cap_, uint8_t* dyn_, const SiaLds& lay_)
+        : a(a_), n(n_), cap(cap_), dyn(dyn_), lay(lay_) {}
 
-    float est[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) est[j] = a.pose_guess[j];
-    float last_cost = 0;
-    bool dbg_done = false;
+    __device__ inline SVO_LDS(float)* kpf(int f) const { return LDSF(dyn + lay.kpf) + f * cap; }
+    __device__ inline SVO_LDS(float)* rec(int f, int px) const { return LDSF(dyn + lay.rec) + (f * 16 + px) * cap; }
 
-    for (int lv = a.cam.max_pyramid_levels; lv > a.cam.min_pyramid_level_pose_estimation; lv--) {
-        const int level = lv - 1;
-        const int divider = 1 << level;
-        const ImgView cur = a.cur[level], prev = a.prev[level];
-        L.fx = a.cam.fx / divider; L.fy = a.cam.fy / divider;
-        L.cx = a.cam.cx / divider; L.cy = a.cam.cy / divider;
-        __syncthreads();                 // everybody is done with the previous level's LDS
-        if (LDS) {
-            uint8_t* sc = dyn + lay.img_cur;
-            for (int i = tid; i < cur.w * cur.h; i += SIA_THREADS) {
-                const int r = i / cur.w, c = i - r * cur.w;
-                mem_st<true>(sc, i, cur.data[(size_t)r * cur.stride + c]);
-            }
-            L.cur = LevelImg<LDS>{sc, cur.w, cur.h, cur.w};
-        } else {
-            L.cur = LevelImg<LDS>{cur.data, cur.w, cur.h, cur.stride};
+    // ---- per-level records (sia_prep_kernel wrote them): HBM -> LDS, 16 B per lane and step
+    __device__ void load_records(int slot) {
+        const float* src = a.rec_ws + (size_t)slot * SIA_REC_ROWS * a.rec_cap;
+        const int c4 = cap >> 2;
+        for (int e = threadIdx.x; e < 67 * c4; e += T) {
+            const int row = e / c4, col = (e - row * c4) * 4;
+            const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)row * a.rec_cap + col);
+            SVO_LDS(float)* dst = row < 64 ? LDSF(dyn + lay.rec) + row * cap + col
+                                           : kpf(KF_GXX + (row - 64)) + col;
+            *(SVO_LDS(v4f)*)dst = v;
         }
-        L.prev = LevelImg<false>{prev.data, prev.w, prev.h, prev.stride};
-        __syncthreads();
+    }
 
-        // ---- per-level records that depend on the previous frame only
-        const int npad = (n * 16 + 63) & ~63;
-        for (int idx = tid; idx < npad; idx += SIA_THREADS) {
-            const int kp = idx >> 4, px = idx & 15;
-            float g0 = 0, g1 = 0, psr = __builtin_nanf(""), i1 = __builtin_nanf("");
-            bool active = false;
-            svo_kp2d kref = {0, 0};
-            if (idx < n * 16) {
-                active = mem_ld<LDS>(L.kp_pt, kp).w != 0.f;
-                kref = a.kps2d[kp];
-                if (level != 0) { kref.x /= divider; kref.y /= divider; }      // setLevel
-            }
-            if (active) {
-                float kx, ky;
-                patch_pos(kref.x - 2.f, kref.y - 2.f, px >> 2, px & 3, kx, ky);
-                // calculate_hessian bounds (:351-352)
-                if (!(((double)kx - 2.0) < 0 || ((double)ky - 2.0) < 0 ||
-                      ((double)kx + 3.0) >= L.prev.w || ((double)ky + 3.0) >= L.prev.h)) {
-                    const float int1 = patch_sum_img(L.prev, kx + 1, ky);
-                    const float int2 = patch_sum_img(L.prev, kx - 1, ky);
-                    const float int3 = patch_sum_img(L.prev, kx, ky + 1);
-                    const float int4 = patch_sum_img(L.prev, kx, ky - 1);
-                    g0 = int1 - int2; g1 = int3 - int4;
-                }
-                // reference half of the residual test (:449-453)
-                if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
-                      ((double)kx + 2.0) > L.prev.w || ((double)ky + 2.0) > L.prev.h))
-                    psr = patch_sum_img(L.prev, kx, ky);
-                // reference half of the cost (image_comparison.cpp:20-88)
-                const int ps = L.patch;
-                const float half_size = ((float)ps - 1.0f) / 2.0f;
-                const float s1x = kref.x - half_size, s1y = kref.y - half_size;
-                const float f1x = floorf(s1x), f1y = floorf(s1y);
-                if (f1x >= 0.f && f1y >= 0.f && f1x < 65536.f && f1y < 65536.f) {
-                    const int ip1x = (int)f1x, ip1y = (int)f1y;
-                    if (ip1y + ps < L.prev.h && ip1x + ps < L.prev.w) {
-                        const float x12 = s1x - (float)ip1x, y12 = s1y - (float)ip1y;
-                        const float x11 = 1.0f - x12, y11 = 1.0f - y12;
-                        const float m0 = x11 * y11, m1 = x12 * y11, m2 = x11 * y12, m3 = x12 * y12;
-                        const int yy = (px >> 2) + ip1y, xx = (px & 3) + ip1x;
-                        float t = 0;
-                        t += m0 * (float)L.prev.at(yy, xx);
-                        t += m1 * (float)L.prev.at(yy, xx + 1);
-                        t += m2 * (float)L.prev.at(yy + 1, xx);
-                        t += m3 * (float)L.prev.at(yy + 1, xx + 1);
-                        i1 = t;
+    // ---- do_calc: project + get_total_intensity_diff
+    __device__ float cost(const float pose[6]) {
+        SIA_T(c0);
+        PoseMats pm;
+        pose_mats(pose, pm);
+        SIA_T(c1);
+        const CamD camd = make_camd(fx, fy, cx, cy, a.cam);
+        const int ps = patch;
+        const float half_size = ((float)ps - 1.0f) / 2.0f;
+        float* buf = reinterpret_cast<float*>(dyn + lay.tbuf) + par * cap;
+        par ^= 1;
+        for (int i = threadIdx.x; i < cap; i += T) {
+            float v = 0;
+            if (kpf(KF_ACT)[i] != 0.f) {
+                const svo_kp2d q = project_point(pm.Rd, pm.t, camd, svo_kp3d{kpf(KF_PX)[i], kpf(KF_PY)[i], kpf(KF_PZ)[i]});
+                kpf(KF_QX)[i] = q.x; kpf(KF_QY)[i] = q.y;
+                const float s2x = q.x - half_size, s2y = q.y - half_size;
+                const float f2x = floorf(s2x), f2y = floorf(s2y);
+                const float i1_0 = rec(REC_I1, 0)[i];
+                // (absurd projections are kept out of the int conversion)
+                if (i1_0 == i1_0 && f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f) {
+                    const int ip2x = (int)f2x, ip2y = (int)f2y;
+                    if (ip2y + ps < cur.h && ip2x + ps < cur.w) {
+                        const float x22 = s2x - (float)ip2x, y22 = s2y - (float)ip2y;
+                        const float x21 = 1.0f - x22, y21 = 1.0f - y22;
+                        const float m0 = x21 * y21, m1 = x22 * y21, m2 = x21 * y22, m3 = x22 * y22;
+                        const int o = ip2y * cur.stride + ip2x;
+                        float b[5][5];
+#pragma unroll
+                        for (int r = 0; r < 5; r++)
+#pragma unroll
+                            for (int c = 0; c < 5; c++) b[r][c] = cur.at(o + r * cur.stride + c);
+#pragma unroll
+                        for (int px = 0; px < 16; px++) {
+                            const int r = px >> 2, c = px & 3;
+                            float i2 = 0;
+                            i2 += m0 * b[r][c];
+                            i2 += m1 * b[r][c + 1];
+                            i2 += m2 * b[r + 1][c];
+                            i2 += m3 * b[r + 1][c + 1];
+                            v += fabsf(rec(REC_I1, px)[i] - i2);
+                        }
                     }
                 }
             }
-            if (idx < n * 16) {
-                mem_st<LDS>(L.rec_i1, idx, i1); mem_st<LDS>(L.rec_g0, idx, g0);
-                mem_st<LDS>(L.rec_g1, idx, g1); mem_st<LDS>(L.rec_ps, idx, psr);
-            }
-            const float gxx = row16_sum_dpp(g0 * g0), gxy = row16_sum_dpp(g0 * g1),
-                        gyy = row16_sum_dpp(g1 * g1);
-            if (px == 0 && idx < n * 16) mem_st<LDS>(L.kp_G, kp, v4f{gxx, gxy, gyy, 0.f});
+            LDSF(buf)[i] = v;                          // inactive / outside: an exact 0
         }
-        __syncthreads();
+        sia_sync<WAVES>();
+        SIA_T(c2);
+        const float total = ordered_sum(buf, n, 0.f);  // diff += ... in keypoint order: same bits in every lane
+        SIA_T(c3);
+        SIA_ADD(1, c1, c0); SIA_ADD(2, c2, c1); SIA_ADD(3, c3, c2); SIA_ADD(4, 1, 0);
+        return total;
+    }
 
-        // ---- estimate_pose_at_level (:166-222); i is shared by both loops.
-        // Every get_gradient(x0) directly follows the cost evaluation of x0 (the
-        // initial one or the accepted trial), so it reuses that rotation/projection.
-        const int maxIter = 50;
-        float x0[6];
+    // ---- get_gradient (with calculate_hessian) at the pose of the LAST cost evaluation
+    // (the projections kept by cost() are reused); the step comes back in grad[6], in every lane
+    __device__ void gradient(const float pose[6], float grad[6], float* dbg) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        SIA_T(g0);
+        PoseMats pm;
+        pose_mats(pose, pm);
+        const bool exact = a.exact_pinv != 0;
+        float acc[27];
 #pragma unroll
-        for (int j = 0; j < 6; j++) x0[j] = est[j];
-        int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0;
-        float prev_cost = sia_cost<LDS>(a, n, L, x0, sh);
-        const float initial = prev_cost;
-        for (int i = 0; i < maxIter; i++) {
-            float* dbg = (a.dbg_H && !dbg_done && level == a.dbg_level) ? a.dbg_H : nullptr;
-            sia_gradient<LDS>(a, n, L, sh, dbg);
-            if (dbg) dbg_done = true;
-            n_grad++;
-            float g[6];
+        for (int q = 0; q < 27; q++) acc[q] = 0;
+        // exact: accumulator of this lane (wave 0): H(r,c) += row_r * row_c, lanes 21..26: b_r -= row_r * diff
+        int ia = 0, ib = 0;
+        if (lane < 21) { ia = c_tri_r[lane]; ib = c_tri_c[lane]; }
+        else if (lane < 27) { ia = lane - 21; ib = 6; }
+        float eacc = 0;
+        constexpr int PS = 64 * 16 + 4;
+        float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index px*64 + lane
+
+        for (int i0 = 0; i0 < cap; i0 += T) {
+            const int i = i0 + tid;
+            float J[12];
 #pragma unroll
-            for (int j = 0; j < 6; j++) g[j] = sh.grad[j];
-            float k = 1.0f;
-            for (; i < maxIter; i++) {
-                float x[6];
+            for (int q = 0; q < 12; q++) J[q] = 0;
+            const bool active = kpf(KF_ACT)[i] != 0.f;
+            if (active) {
+                float X[3] = {kpf(KF_PX)[i] - pm.t[0], kpf(KF_PY)[i] - pm.t[1], kpf(KF_PZ)[i] - pm.t[2]};
+                mat33f_vec(pm.Ri, X, X);
+                pose_jacobian(fx, fy, X[0], X[1], X[2], J);
+            }
+            // residuals: the same walk over the patch as above, from the projection
+            float d[16];
+            {
+                float kx = kpf(KF_QX)[i] - 2.f, ky = kpf(KF_QY)[i] - 2.f;
 #pragma unroll
-                for (int j = 0; j < 6; j++) x[j] = x0[j] + k * g[j];
-                const float new_cost = sia_cost<LDS>(a, n, L, x, sh);
-                n_cost++;
-                if (new_cost < prev_cost) {
+                for (int r = 0; r < 4; r++) {
 #pragma unroll
-                    for (int j = 0; j < 6; j++) x0[j] = x[j];
-                    prev_cost = new_cost;
-                    accepted++;
-                    break;
-                } else if ((double)fabsf(new_cost - prev_cost) < 1.0) {
-                    i = maxIter;
-                    exit_small = 1;
-                    break;
-                } else
-                    k /= 2;
+                    for (int c = 0; c < 4; c++) {
+                        const int px = r * 4 + c;
+                        float dd = 0;
+                        if (active) {
+                            const float psr = rec(REC_PS, px)[i];
+                            if (psr == psr &&                   // reference pixel inside (:449-451)
+                                !(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
+                                  ((double)kx + 2.0) > cur.w || ((double)ky + 2.0) > cur.h))
+                                dd = patch_sum_lds(cur, kx, ky) - psr;
+                        }
+                        d[px] = dd;
+                        kx += 1.f;
+                    }
+                    kx -= 4.f;
+                    ky += 1.f;
+                }
+            }
+            if (!exact) {
+                float s0 = 0, s1 = 0, Gxx = 0, Gxy = 0, Gyy = 0;
+                if (active) {                               // (slots past the keypoints hold no records)
+#pragma unroll
+                    for (int px = 0; px < 16; px++) {
+                        s0 += rec(REC_G0, px)[i] * d[px];
+                        s1 += rec(REC_G1, px)[i] * d[px];
+                    }
+                    Gxx = kpf(KF_GXX)[i]; Gxy = kpf(KF_GXY)[i]; Gyy = kpf(KF_GYY)[i];
+                }
+                int q = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = r; c < 6; c++) {          // H(r,c) = J_r^T (G J)_c
+                        const float mm0 = Gxx * J[c] + Gxy * J[6 + c], mm1 = Gxy * J[c] + Gyy * J[6 + c];
+                        acc[q++] += J[r] * mm0 + J[6 + r] * mm1;
+                    }
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[21 + r] -= J[r] * s0 + J[6 + r] * s1;
+            } else {
+                // One wave at a time stages the rows of gradient_times_jacobians (:376-388) and the
+                // diffs of its 64 keypoints, pixel-major; wave 0 adds them in storage order.
+                for (int w = 0; w < WAVES; w++) {
+                    sia_sync<WAVES>();                      // the previous 64 keypoints have been consumed
+                    if (wave == w) {
+#pragma unroll
+                        for (int px = 0; px < 16; px++) {
+                            const float g0 = active ? rec(REC_G0, px)[i] : 0.f, g1 = active ? rec(REC_G1, px)[i] : 0.f;
+#pragma unroll
+                            for (int q = 0; q < 6; q++) {
+                                float sum = 0;
+                                sum += g0 * J[q];
+                                sum += g1 * J[6 + q];
+                                LDSF(stage)[q * PS + px * 64 + lane] = sum;
+                            }
+                            LDSF(stage)[6 * PS + px * 64 + lane] = d[px];
+                        }
+                    }
+                    sia_sync<WAVES>();
+                    if (wave == 0 && lane < 27) {
+                        const int m = min(64, n - (i0 + w * 64));   // keypoints of this chunk, in index order
+                        const SVO_LDS(float)* pa = LDSCF(stage) + ia * PS;
+                        const SVO_LDS(float)* pb = LDSCF(stage) + ib * PS;
+                        if (lane < 21) {
+                            for (int j = 0; j < m; j++)
+#pragma unroll
+                                for (int px = 0; px < 16; px++) eacc += pa[px * 64 + j] * pb[px * 64 + j];
+                        } else {
+                            for (int j = 0; j < m; j++)
+#pragma unroll
+                                for (int px = 0; px < 16; px++) eacc -= pa[px * 64 + j] * pb[px * 64 + j];
+                        }
+                    }
+                }
             }
         }
+
+        SIA_T(g1);
+        float* sums = reinterpret_cast<float*>(dyn + lay.sums);        // [WAVES][32]
+        float H[36], b[6];
+        if (!exact) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) est[j] = x0[j];
-        last_cost = prev_cost;
-        if (tid == 0 && a.trace) {
-            svo_gn_trace t;
-            t.level = level; t.n_gradient = n_grad; t.n_cost = n_cost; t.n_accepted = accepted;
-            t.exit_small = exit_small; t.initial_cost = initial; t.final_cost = prev_cost;
-            for (int j = 0; j < 6; j++) t.pose[j] = x0[j];
-            a.trace[level] = t;
+            for (int q = 0; q < 27; q++) acc[q] = wave_sum_dpp(acc[q]);
+            if constexpr (WAVES > 1) {
+                __syncthreads();
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 27; q++) LDSF(sums)[wave * 32 + q] = acc[q];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 27; q++) {
+                    float v = LDSCF(sums)[q];
+#pragma unroll
+                    for (int w = 1; w < WAVES; w++) v += LDSCF(sums)[w * 32 + q];
+                    acc[q] = v;
+                }
+            }
+        } else {
+            sia_sync<WAVES>();
+            if (wave == 0 && lane < 27) LDSF(sums)[lane] = eacc;
+            sia_sync<WAVES>();
+#pragma unroll
+            for (int q = 0; q < 27; q++) acc[q] = LDSCF(sums)[q];
+        }
+        {
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) { H[r * 6 + c] = acc[q]; H[c * 6 + r] = acc[q]; q++; }
+#pragma unroll
+            for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
+        }
+        SIA_T(g2);
+        float delta[6], pg[6];
+        gn_solve6(H, b, delta, exact);
+        exponential_map(delta, pg);
+        mat33f_vec(pm.R, pg, grad);                  // pose_estimator.cpp:495-497
+        mat33f_vec(pm.R, pg + 3, grad + 3);
+        SIA_T(g3);
+        SIA_ADD(5, g1, g0); SIA_ADD(6, g2, g1); SIA_ADD(7, g3, g2); SIA_ADD(8, 1, 0);
+#ifndef SVO_SIA_STAMPS
+        if (dbg && tid == 0) {
+            for (int q = 0; q < 36; q++) dbg[q] = H[q];
+            for (int q = 0; q < 6; q++) { dbg[36 + q] = b[q]; dbg[42 + q] = grad[q]; }
+        }
+#else
+        (void)dbg;
+#endif
+    }
+
+    // stage one level image into LDS (rows padded to a dword)
+    __device__ void stage_image(const ImgView im) {
+        const int tid = threadIdx.x;
+        uint8_t* sc = dyn + lay.img;
+        const int ls = (im.w + 3) & ~3;
+        if ((((uintptr_t)im.data | (uintptr_t)im.stride) & 3) == 0) {
+            const int wd = im.w >> 2;                       // whole dwords per row
+            for (int i = tid; i < wd * im.h; i += T) {
+                const int r = i / wd, c = i - r * wd;
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(im.data + (size_t)r * im.stride + 4 * c);
+                *(SVO_LDS(uint32_t)*)(sc + r * ls + 4 * c) = v;
+            }
+            const int tail = im.w & 3;
+            for (int i = tid; i < tail * im.h; i += T) {
+                const int r = i / tail, c = wd * 4 + (i - r * tail);
+                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.data[(size_t)r * im.stride + c];
+            }
+        } else {
+            for (int i = tid; i < im.w * im.h; i += T) {
+                const int r = i / im.w, c = i - r * im.w;
+                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.data[(size_t)r * im.stride + c];
+            }
+        }
+        cur = LevelImg{sc, im.w, im.h, ls};
+    }
+
+    __device__ void run() {
+        const int tid = threadIdx.x;
+        patch = a.cam.window_size_pose_estimator;
+        // active set and points (PoseEstimatorCallback ctor, :238-245)
+        for (int i = tid; i < cap; i += T) {
+            const bool active = i < n && !(a.flags && (a.flags[i] & SVO_IGNORE_TEMPORARY));
+            svo_kp3d P = {0, 0, 0};
+            if (active) P = a.kps3d[i];
+            kpf(KF_PX)[i] = P.x; kpf(KF_PY)[i] = P.y; kpf(KF_PZ)[i] = P.z;
+            kpf(KF_QX)[i] = 0; kpf(KF_QY)[i] = 0;
+            kpf(KF_ACT)[i] = active ? 1.f : 0.f;
+        }
+        SIA_T(k0);
+        float est[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) est[j] = a.pose_guess[j];
+        float last_cost = 0;
+        bool dbg_done = false;
+
+        for (int lv = a.cam.max_pyramid_levels; lv > a.cam.min_pyramid_level_pose_estimation; lv--) {
+            const int level = lv - 1;
+            const int divider = 1 << level;
+            fx = a.cam.fx / divider; fy = a.cam.fy / divider;
+            cx = a.cam.cx / divider; cy = a.cam.cy / divider;
+            sia_sync<WAVES>();               // everybody is done with the previous level's image
+            SIA_T(l0);
+            stage_image(a.cur[level]);
+            load_records(level - a.cam.min_pyramid_level_pose_estimation);
+            sia_sync<WAVES>();
+            SIA_T(l1);
+            SIA_ADD(0, l1, l0);
+
+            // ---- estimate_pose_at_level (:166-222); i is shared by both loops.
+            // Every get_gradient(x0) directly follows the cost evaluation of x0 (the
+            // initial one or the accepted trial), so it reuses that projection.
+            const int maxIter = 50;
+            float x0[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) x0[j] = est[j];
+            int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0;
+            float prev_cost = cost(x0);
+            const float initial = prev_cost;
+            for (int i = 0; i < maxIter; i++) {
+                float* dbg = (a.dbg_H && !dbg_done && level == a.dbg_level) ? a.dbg_H : nullptr;
+                float g[6];
+                gradient(x0, g, dbg);
+                if (dbg) dbg_done = true;
+                n_grad++;
+                float k = 1.0f;
+                for (; i < maxIter; i++) {
+                    float x[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) x[j] = x0[j] + k * g[j];
+                    const float new_cost = cost(x);
+                    n_cost++;
+                    if (new_cost < prev_cost) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) x0[j] = x[j];
+                        prev_cost = new_cost;
+                        accepted++;
+                        break;
+                    } else if ((double)fabsf(new_cost - prev_cost) < 1.0) {
+                        i = maxIter;
+                        exit_small = 1;
+                        break;
+                    } else
+                        k /= 2;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) est[j] = x0[j];
+            last_cost = prev_cost;
+            if (tid == 0 && a.trace) {
+                svo_gn_trace t;
+                t.level = level; t.n_gradient = n_grad; t.n_cost = n_cost; t.n_accepted = accepted;
+                t.exit_small = exit_small; t.initial_cost = initial; t.final_cost = prev_cost;
+                for (int j = 0; j < 6; j++) t.pose[j] = x0[j];
+                a.trace[level] = t;
+            }
+        }
+#ifdef SVO_SIA_STAMPS
+        if (tid == 0 && a.dbg_H) {
+            st[9] = __builtin_readcyclecounter() - k0;
+            for (int j = 0; j < 12; j++) a.dbg_H[j] = (float)st[j];
+        }
+#endif
+        if (tid == 0) {
+            for (int j = 0; j < 6; j++) a.pose_out[j] = est[j];
+            if (a.cost_out) *a.cost_out = last_cost;
+            if (a.mats_out) {    // once per sequence instead of once per keypoint workgroup of klt_track_kernel
+                PoseMats pm;
+                pose_mats(est, pm);
+                *a.mats_out = pm;
+            }
         }
     }
-    if (tid == 0) {
-        for (int j = 0; j < 6; j++) a.pose_out[j] = est[j];
-        if (a.cost_out) *a.cost_out = last_cost;
-        if (a.mats_out) {    // once per sequence instead of once per keypoint workgroup of klt_track_kernel
-            PoseMats pm;
-            pose_mats(est, pm);
-            *a.mats_out = pm;
-        }
-    }
-}
+};
 
-__global__ __launch_bounds__(SIA_THREADS) void sia_gn_kernel(const SiaArgs* __restrict__ args,
-                                                              int max_img_bytes, int lds_bytes) {
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sia_gn_kernel(const SiaArgs* __restrict__ args, int img_bytes, int cap) {
     const SiaArgs& a = args[blockIdx.x];
-    const int n = min(*a.n_ptr, a.cap);
-    __shared__ SiaShared sh;
+    const int n = min(*a.n_ptr, cap);
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    const SiaLds lay = sia_lds_layout(n, max_img_bytes);
-#ifdef SVO_SIA_STAMPS
-    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) sh.stamp[i] = 0;
-    const long long k0 = __builtin_readcyclecounter();
-#endif
-    // the whole working set in LDS when this frame's keypoints fit, else the HBM workspace
-    if (max_img_bytes > 0 && lay.total <= (size_t)lds_bytes) sia_run<true>(a, n, sh, dyn, lay);
-    else sia_run<false>(a, n, sh, dyn, lay);
-#ifdef SVO_SIA_STAMPS
-    if (threadIdx.x == 0 && a.dbg_H) {   // diagnostic build: the debug buffer carries cycle counts
-        sh.stamp[10] = __builtin_readcyclecounter() - k0;
-        for (int i = 0; i < 12; i++) a.dbg_H[i] = (float)sh.stamp[i];
-    }
-#endif
+    const SiaLds lay = sia_lds_layout(img_bytes, cap, 64 * WAVES, a.exact_pinv != 0);
+    Sia<WAVES> s(a, n, cap, dyn, lay);
+    s.run();
 }
 
-// largest level image the estimator uses, if two copies of it plus a minimal
-// working set (64 keypoints) fit the LDS budget; 0: run from HBM
-static int sia_max_img_bytes(const svo_camera_settings& cam, int width, int height) {
+// largest level image the estimator uses (LDS rows padded to a dword)
+static int sia_img_bytes(const svo_camera_settings& cam, int width, int height) {
     int best = 0;
     for (int lv = cam.max_pyramid_levels; lv > cam.min_pyramid_level_pose_estimation; lv--) {
         const int level = lv - 1;
-        const int b = (width >> level) * (height >> level);
+        const int b = (((width >> level) + 3) & ~3) * (height >> level);
         if (b > best) best = b;
     }
-    return sia_lds_layout(64, best).total <= SIA_LDS_BUDGET ? best : 0;
+    return best;
 }
 
-// Dynamic LDS of a launch: the working set of `n_bound` keypoints (the host's upper bound for every
-// sequence of the launch), not the whole budget, so that two or three alignment workgroups — or an
-// alignment workgroup and the window kernels of another sequence group — share a CU's 160 KB.
-size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int n_bound) {
-    const int img = sia_max_img_bytes(cam, width, height);
-    if (img <= 0) return 0;
-    const size_t need = sia_lds_layout(std::max(n_bound, 16), img).total;
-    return need <= SIA_LDS_BUDGET ? need : SIA_LDS_BUDGET;   // a sequence above the bound runs from HBM
-}
-
-void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
-                int height, int n_bound, hipStream_t stream) {
-    static std::atomic<size_t> configured{0};
-    const int img = sia_max_img_bytes(cam, width, height);
-    const size_t lds_bytes = sia_lds_bytes(cam, width, height, n_bound);
-    if (lds_bytes > configured.load()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel),
+template <int WAVES>
+static void sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap, size_t lds, hipStream_t stream) {
+    static std::atomic<bool> configured{false};
+    if (!configured.exchange(true))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIA_LDS_BUDGET);
-        configured.store(SIA_LDS_BUDGET);
+    hipLaunchKernelGGL((sia_gn_kernel<WAVES>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
+}
+
+void launch_sia_big(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+                    int height, int n_bound, hipStream_t stream);   // sia_big.hip
+
+// Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints. Many sequences:
+// few waves (several sequences per CU, little redundant uniform work); a lone sequence: one
+// keypoint per lane as long as the waves last.
+void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+                int height, int n_bound, int rec_cap, int exact, hipStream_t stream) {
+    const int nb = std::max(n_bound, 1);
+    int waves;
+    if (batch >= 16) waves = nb <= 128 ? 1 : nb <= 256 ? 2 : 4;
+    else waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
+    const int T = 64 * waves;
+    const int cap = (nb + T - 1) / T * T;             // every lane of every pass owns a slot
+    const int img = sia_img_bytes(cam, width, height);
+    const size_t lds = sia_lds_layout(img, cap, 64 * waves, exact != 0).total;
+    if (lds > SIA_LDS_BUDGET || cap > rec_cap) {
+        launch_sia_big(d_args, batch, cam, width, height, n_bound, stream);
+        return;
     }
-    hipLaunchKernelGGL(sia_gn_kernel, dim3(batch), dim3(SIA_THREADS), lds_bytes, stream, d_args, img, (int)lds_bytes);
+    const int n_lv = cam.max_pyramid_levels - cam.min_pyramid_level_pose_estimation;
+    hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 255) / 256, n_lv, batch), dim3(256), 0, stream, d_args);
+    switch (waves) {
+        case 1: sia_launch_shape<1>(d_args, batch, img, cap, lds, stream); break;
+        case 2: sia_launch_shape<2>(d_args, batch, img, cap, lds, stream); break;
+        case 4: sia_launch_shape<4>(d_args, batch, img, cap, lds, stream); break;
+        default: sia_launch_shape<8>(d_args, batch, img, cap, lds, stream); break;
+    }
+}
+
+size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap) {
+    return (size_t)(cam.max_pyramid_levels - cam.min_pyramid_level_pose_estimation) * SIA_REC_ROWS * rec_cap;
 }
 
 }  // namespace svo

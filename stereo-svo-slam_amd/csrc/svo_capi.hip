@@ -50,6 +50,8 @@ struct svo_handle {
     size_t ring_cap, ring_off;
     float4* sia_cache;   // [max_kps*16]
     float* sia_kpws;     // [max_kps*8]
+    float* sia_rec;      // [7][68][rec_cap] per-level alignment records
+    int rec_cap;
     KfDev* kf_one;       // 1-entry keyframe table for svo_klt_track
     int exact_pinv;
 };
@@ -76,6 +78,8 @@ extern "C" int svo_handle_create(int device, int max_keypoints, svo_handle** out
     HIP_TRY(hipMalloc(&h->sia_cache, sizeof(float4) * 16 * (size_t)max_keypoints));
     HIP_TRY(hipMalloc(&h->sia_kpws, sizeof(float) * 40 * (size_t)(max_keypoints + 16)));
     HIP_TRY(hipMalloc(&h->kf_one, sizeof(KfDev)));
+    h->rec_cap = (max_keypoints + 511) / 512 * 512;
+    HIP_TRY(hipMalloc(&h->sia_rec, sizeof(float) * 7 * 68 * (size_t)h->rec_cap));
     *out = h;
     return SVO_OK;
 }
@@ -87,6 +91,7 @@ extern "C" int svo_handle_destroy(svo_handle* h) {
     (void)hipFree(h->ring);
     (void)hipFree(h->sia_cache);
     (void)hipFree(h->sia_kpws);
+    (void)hipFree(h->sia_rec);
     (void)hipFree(h->kf_one);
     delete h;
     return SVO_OK;
@@ -192,6 +197,8 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     if (cam->max_pyramid_levels < 1 || cam->max_pyramid_levels > 7 ||
         cam->min_pyramid_level_pose_estimation < 0)
         return fail(SVO_ERR_INVALID, "svo_sparse_align: max_pyramid_levels must be 1..7");
+    if (cam->window_size_pose_estimator != 4)   // PATCH_SIZE, src/lib/pose_estimator.cpp:68
+        return fail(SVO_ERR_INVALID, "svo_sparse_align: window_size_pose_estimator must be 4");
     SiaArgs sa;
     memset(&sa, 0, sizeof(sa));
     for (int l = 0; l < cam->max_pyramid_levels; l++) {
@@ -206,13 +213,14 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     sa.kps2d = kps2d; sa.kps3d = kps3d; sa.flags = flags;
     sa.pose_guess = pose_guess; sa.pose_out = pose_out; sa.cost_out = cost; sa.trace = trace;
     sa.cache = h->sia_cache; sa.kp_ws = h->sia_kpws;
+    sa.rec_ws = h->sia_rec; sa.rec_cap = h->rec_cap;
     sa.dbg_H = dbg; sa.dbg_level = dbg_level;
     sa.cap = h->max_kps;
     sa.exact_pinv = h->exact_pinv;
     SiaArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
-    launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->stream);
+    launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->rec_cap, h->exact_pinv, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

@@ -169,6 +169,7 @@ struct KfHost {
     float pose[6];
     int n;
     svo_kp2d* kps2d; svo_kp3d* kps3d; uint32_t* flags; int* outl; int* inl;   // device
+    int* kf_id; int* kp_index; float* score; int* level_type; uint32_t* color; float* kfx; float* kfP;
 };
 
 struct Seq {
@@ -180,6 +181,7 @@ struct Seq {
     uint8_t* klt_status = nullptr;
     float* disparity = nullptr;
     float4* sia_cache = nullptr;
+    float* sia_rec = nullptr;        // per-level alignment records (sia_prep_kernel)
     float* sia_kpws = nullptr;
     PoseMats* sia_mats = nullptr;    // rotation matrices of the aligned pose (sia_gn_kernel -> klt_track_kernel)
     KfDev* d_kfs = nullptr;
@@ -276,7 +278,7 @@ private:
 }  // namespace
 
 struct svo_group {
-    int device, B, width, height, cap, max_kf, n_lk, det_levels, max_cells, merge_cells;
+    int device, B, width, height, cap, rec_cap, max_kf, n_lk, det_levels, max_cells, merge_cells;
     svo_camera_settings cam;
     hipStream_t stream;
     std::vector<Seq> seqs;
@@ -294,12 +296,13 @@ struct svo_group {
     // copy) and are then ingested like device-resident ones
     uint8_t* d_stage_in = nullptr; size_t stage_frame_bytes = 0;
     size_t readback_bytes = 0;
-    size_t sia_lds = 0;
     bool timing = false;
+    bool failed = false;
     int exact_pinv = 0;
     hipEvent_t ev[10] = {nullptr};
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
+    std::vector<uint8_t*> kf_slabs;   // free per-keyframe keypoint storage (allocated in chunks)
     svo_totals totals;
     HostPool* pool = nullptr;
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
@@ -401,20 +404,42 @@ T* args_at(svo_group* c, size_t off, int s) { return reinterpret_cast<T*>(c->h_a
 template <typename T>
 T* dargs_at(svo_group* c, size_t off, int s = 0) { return reinterpret_cast<T*>(c->d_args + off) + s; }
 
+// per-keyframe keypoint storage: 15 dwords per keypoint. Slabs come from chunks of `count`
+// (one hipMalloc — a device-wide synchronising call — per chunk, not per keyframe).
+size_t kf_slab_bytes(const svo_group* c) { return align_up((size_t)c->cap * 15 * 4, 256); }
+
+int grow_kf_slabs(svo_group* c, int count) {
+    const size_t sb = kf_slab_bytes(c);
+    uint8_t* base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), sb * count));
+    c->allocs.push_back(base);
+    for (int i = count - 1; i >= 0; i--) c->kf_slabs.push_back(base + sb * i);
+    return SVO_OK;
+}
+
 int new_keyframe_storage(svo_group* c, Seq& q, int s, int id) {
     if (id >= c->max_kf) return svo_set_error(SVO_ERR_CAPACITY, "more than %d keyframes", c->max_kf);
     KfHost k;
     std::memset(&k, 0, sizeof(k));
     const size_t cap = c->cap;
-    const size_t bytes = cap * (sizeof(svo_kp2d) + sizeof(svo_kp3d) + 3 * sizeof(int));
-    uint8_t* base = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
-    c->allocs.push_back(base);
+    if (c->kf_slabs.empty()) {
+        const int rc = grow_kf_slabs(c, std::max(c->B, 32));
+        if (rc) return rc;
+    }
+    uint8_t* base = c->kf_slabs.back();
+    c->kf_slabs.pop_back();
     k.kps3d = reinterpret_cast<svo_kp3d*>(base);
     k.kps2d = reinterpret_cast<svo_kp2d*>(base + cap * sizeof(svo_kp3d));
     k.flags = reinterpret_cast<uint32_t*>(base + cap * (sizeof(svo_kp3d) + sizeof(svo_kp2d)));
     k.outl = reinterpret_cast<int*>(k.flags + cap);
     k.inl = k.outl + cap;
+    k.kf_id = k.inl + cap;
+    k.kp_index = k.kf_id + cap;
+    k.score = reinterpret_cast<float*>(k.kp_index + cap);
+    k.level_type = reinterpret_cast<int*>(k.score + cap);
+    k.color = reinterpret_cast<uint32_t*>(k.level_type + cap);
+    k.kfx = reinterpret_cast<float*>(k.color + cap);
+    k.kfP = k.kfx + cap;
     k.set = q.cur_set;
     q.cur_set->refs++;
     q.kfs.push_back(k);
@@ -423,6 +448,8 @@ int new_keyframe_storage(svo_group* c, Seq& q, int s, int id) {
     for (int l = 0; l < c->n_lk; l++) d.lk[l] = q.cur_set->lk[l];
     d.n_lk = c->n_lk;
     d.kps2d = k.kps2d; d.kps3d = k.kps3d; d.flags = k.flags; d.outlier_count = k.outl; d.inlier_count = k.inl;
+    d.kf_id = k.kf_id; d.kp_index = k.kp_index; d.score = k.score; d.level_type = k.level_type;
+    d.color = k.color; d.kfx = k.kfx; d.kfP = k.kfP;
     HIP_TRY(hipMemcpyAsync(q.d_kfs + id, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
     return SVO_OK;
 }
@@ -470,6 +497,8 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
         cam->window_size_depth_calculator < 1 || cam->window_size_depth_calculator > 35 ||
         cam->search_x < 0 || cam->search_x > 64 || cam->search_y < 0 || cam->search_y > 8)
         return svo_set_error(SVO_ERR_INVALID, "windows <= 35, search_x <= 64, search_y <= 8 supported");
+    if (cam->window_size_pose_estimator != 4)   // PATCH_SIZE, src/lib/pose_estimator.cpp:68
+        return svo_set_error(SVO_ERR_INVALID, "window_size_pose_estimator must be 4");
     if (cam->grid_width < 4 || cam->grid_height < 4 || cam->grid_width > 96 || cam->grid_height > 64)
         return svo_set_error(SVO_ERR_INVALID, "grid cell must be within 4..96 x 4..64");
     int count = 0;
@@ -484,6 +513,7 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int cells = (width / cam->grid_width) * (height / cam->grid_height);
     c->cap = (int)align_up((size_t)(2 * cells + 128), 64);
+    c->rec_cap = (int)align_up((size_t)c->cap, 512);   // whole passes of the widest alignment workgroup
     c->max_kf = 4096;
     // usable LK levels (cv::buildOpticalFlowPyramid stops at levels not larger than the window)
     {
@@ -504,7 +534,6 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     }
     c->merge_cells = ((width + cam->grid_height - 1) / cam->grid_height) *
                      ((height + cam->grid_width - 1) / cam->grid_width);
-    c->sia_lds = sia_lds_bytes(*cam, width, height, c->cap);
 
     const int B = c->B;
     // argument blocks
@@ -562,6 +591,7 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
         if ((rc = dev_alloc(c, &q.klt_status, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.disparity, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.sia_cache, (size_t)c->cap * 16))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_rec, sia_rec_ws_floats(*cam, c->rec_cap)))) return rc;
         if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)(c->cap + 16) * 40))) return rc;
         if ((rc = dev_alloc(c, &q.sia_mats, 1))) return rc;
         if ((rc = dev_alloc(c, &q.d_kfs, (size_t)c->max_kf))) return rc;
@@ -582,6 +612,7 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
             q.free_sets.push_back(is);
         }
     }
+    if ((rc = grow_kf_slabs(c, std::max(2 * B, 32)))) return rc;   // the first keyframes never allocate
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return SVO_OK;
@@ -687,10 +718,8 @@ static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool fi
     return SVO_OK;
 }
 
-static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_t* const* right,
-                              int stride, const float* time_stamps, int mem) {
-    if (!c || !left || !right || !time_stamps || stride < c->width)
-        return svo_set_error(SVO_ERR_INVALID, "svo_new_images: bad arguments");
+static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const uint8_t* const* right,
+                                  int stride, const float* time_stamps, int mem) {
     HIP_TRY(hipSetDevice(c->device));
     const auto wall0 = std::chrono::steady_clock::now();
     const int B = c->B;
@@ -782,6 +811,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
             sa->cam = c->cam; sa->n_ptr = k.n; sa->kps2d = k.kps2d; sa->kps3d = k.kps3d; sa->flags = k.flags;
             sa->pose_guess = d_guess; sa->pose_out = dr->pose_sia; sa->cost_out = &dr->sia_cost;
             sa->trace = dr->sia_trace; sa->cache = q.sia_cache; sa->kp_ws = q.sia_kpws;
+            sa->rec_ws = q.sia_rec; sa->rec_cap = c->rec_cap;
             sa->mats_out = q.sia_mats;
             sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap; sa->exact_pinv = c->exact_pinv;
             KltArgs* ka = args_at<KltArgs>(c, c->off_klt, s);
@@ -844,7 +874,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
         int grid_n = 1;
         for (int s = 0; s < B; s++) grid_n = std::max(grid_n, c->seqs[s].n_host);
         grid_n = std::min(grid_n, c->cap);
-        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, grid_n, c->stream);
+        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream);
         SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, grid_n, c->cam.window_size_opt_flow, c->stream);
         SVO_MARK(4);
@@ -889,6 +919,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
     const float sia_ms = stage_ms[2];
 
     // ---- host bookkeeping (stereo_slam.cpp:250-270); the pose filter itself is deferred
+    int overflow_seq = -1;
     for (int s = 0; s < B; s++) {
         Seq& q = c->seqs[s];
         const FrameResult& r = c->h_res[s];
@@ -930,7 +961,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
                 c->totals.gn_gradient_calls += r.sia_trace[l].n_gradient;
                 c->totals.gn_cost_calls += r.sia_trace[l].n_cost;
             }
-        if (r.overflow) return svo_set_error(SVO_ERR_CAPACITY, "sequence %d: more than %d keypoints", s, c->cap);
+        if (r.overflow && overflow_seq < 0) overflow_seq = s;     // reported after every sequence is booked
     }
     hlap(6);   // bookkeeping
     c->host_steps++;
@@ -938,7 +969,22 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
     for (int i = 0; i < 8; i++) c->totals.stage_ms[i] += stage_ms[i];
     c->totals.wall_ms +=
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (overflow_seq >= 0)
+        return svo_set_error(SVO_ERR_CAPACITY, "sequence %d: more than %d keypoints", overflow_seq, c->cap);
     return SVO_OK;
+}
+
+// A frame that fails half way (HIP error, capacity) leaves the sequences of the group at mixed
+// frame ids: the group is marked failed and rejects further frames instead of tracking on.
+static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_t* const* right,
+                          int stride, const float* time_stamps, int mem) {
+    if (!c || !left || !right || !time_stamps || stride < c->width)
+        return svo_set_error(SVO_ERR_INVALID, "svo_new_images: bad arguments");
+    if (c->failed)
+        return svo_set_error(SVO_ERR_INVALID, "svo_new_images: an earlier frame of this ctx failed; create a new ctx");
+    const int rc = grp_new_images_impl(c, left, right, stride, time_stamps, mem);
+    if (rc != SVO_OK) c->failed = true;
+    return rc;
 }
 
 static int grp_get_totals(svo_group* c, svo_totals* out) {
@@ -1029,8 +1075,8 @@ static int grp_get_keyframe(svo_group* c, int seq, int id, svo_kp2d* kps2d, svo_
     const KfHost& k = q.kfs[id];
     if (n) *n = k.n;
     if (pose) std::memcpy(pose, k.pose, sizeof(float) * 6);
-    return fetch_info(c, std::min(cap, k.n), k.kps2d, k.kps3d, k.flags, nullptr, nullptr, k.outl, k.inl,
-                      nullptr, nullptr, nullptr, nullptr, nullptr, kps2d, kps3d, info);
+    return fetch_info(c, std::min(cap, k.n), k.kps2d, k.kps3d, k.flags, k.kf_id, k.kp_index, k.outl, k.inl,
+                      k.kfx, k.kfP, k.score, k.level_type, k.color, kps2d, kps3d, info);
 }
 
 static int grp_get_trajectory(svo_group* c, int seq, svo_pose* out, int cap, int* n) {

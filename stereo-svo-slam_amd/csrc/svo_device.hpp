@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/svo_types.h"
+#include "../../include/svo_libm.h"
 
 namespace svo {
 
@@ -117,7 +118,7 @@ __device__ inline void rodrigues_d(const float r[3], double R[9]) {
         return;
     }
     double s, c;
-    sincos(theta, &s, &c);
+    svo_sincos(theta, &s, &c);   // the same polynomial as the oracle: include/svo_libm.h
     const double c1 = 1.0 - c;
     const double itheta = 1.0 / theta;
     rx *= itheta; ry *= itheta; rz *= itheta;
@@ -264,7 +265,7 @@ __host__ __device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], flo
                 for (int k = 0; k < M; k++) p += (double)At[i][k] * At[j][k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                const double beta = a - b, gamma = hypot(p, beta);
+                const double beta = a - b, gamma = svo_hypot(p, beta);
                 float c, s;
                 if (beta < 0) {
                     const double delta = (gamma - beta) * 0.5;
@@ -314,31 +315,134 @@ __host__ __device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], flo
     }
 }
 
+// The same one-sided Jacobi SVD for the 6x6 systems of the Gauss-Newton kernels, written so
+// that every array index is a compile-time constant (all loops over rows / columns / pairs are
+// unrolled, the selection sort swaps under predicates): At, Vt and W live in registers instead of
+// scratch memory. Same operations in the same order as jacobi_svd<6,6>: same bits.
+__device__ inline void jacobi_svd6_reg(float (&At)[6][6], float (&W)[6], float (&Vt)[6][6]) {
+    const float eps = FLT_EPSILON * 2;
+    double Wd[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        Wd[i] = sd;
+#pragma unroll
+        for (int k = 0; k < 6; k++) Vt[i][k] = (i == k) ? 1.f : 0.f;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) {
+                double a = Wd[i], p = 0, b = Wd[j];
+#pragma unroll
+                for (int k = 0; k < 6; k++) p += (double)At[i][k] * At[j][k];
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = svo_hypot(p, beta);
+                    float c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = (float)sqrt(delta / gamma);
+                        c = (float)(p / (gamma * s * 2));
+                    } else {
+                        c = (float)sqrt((gamma + beta) / (gamma * 2));
+                        s = (float)(p / (gamma * c * 2));
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const float t0 = c * At[i][k] + s * At[j][k];
+                        const float t1 = -s * At[i][k] + c * At[j][k];
+                        At[i][k] = t0; At[j][k] = t1;
+                        a += (double)t0 * t0; b += (double)t1 * t1;
+                    }
+                    Wd[i] = a; Wd[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const float t0 = c * Vt[i][k] + s * Vt[j][k];
+                        const float t1 = -s * Vt[i][k] + c * Vt[j][k];
+                        Vt[i][k] = t0; Vt[j][k] = t1;
+                    }
+                }
+            }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        Wd[i] = sqrt(sd);
+    }
+    // selection sort, largest first: row i <-> the first maximum of rows i..5
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        int j = i;
+        double wj = Wd[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++)
+            if (wj < Wd[k]) { j = k; wj = Wd[k]; }
+#pragma unroll
+        for (int k = i + 1; k < 6; k++)
+            if (j == k) {
+                const double tw = Wd[i]; Wd[i] = Wd[k]; Wd[k] = tw;
+#pragma unroll
+                for (int q = 0; q < 6; q++) { const float t = At[i][q]; At[i][q] = At[k][q]; At[k][q] = t; }
+#pragma unroll
+                for (int q = 0; q < 6; q++) { const float t = Vt[i][q]; Vt[i][q] = Vt[k][q]; Vt[k][q] = t; }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        W[i] = (float)Wd[i];
+        const double sd = Wd[i];
+        const float s = (float)(sd > (double)FLT_MIN ? 1 / sd : 0.);
+#pragma unroll
+        for (int k = 0; k < 6; k++) At[i][k] *= s;
+    }
+}
+
 // Matx66f::inv(DECOMP_SVD): zeros when sigma_max < FLT_EPSILON or
 // sigma_min / sigma_max == 0, else V diag(1/w) U^T with the SVBkSb threshold.
-__device__ __attribute__((noinline)) void inv_svd6(const float H[36], float Hinv[36]) {
+__device__ inline void inv_svd6(const float H[36], float Hinv[36]) {
     float At[6][6], Vt[6][6], W[6];
+#pragma unroll
     for (int i = 0; i < 6; i++)
+#pragma unroll
         for (int j = 0; j < 6; j++) At[i][j] = H[j * 6 + i];
-    jacobi_svd<6, 6>(At, W, Vt);
+    jacobi_svd6_reg(At, W, Vt);
+#pragma unroll
     for (int i = 0; i < 36; i++) Hinv[i] = 0;
     double threshold = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) threshold += W[i];
     threshold *= (float)(DBL_EPSILON * 2);
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         double wi = W[i];
-        if (fabs(wi) <= threshold) continue;
-        wi = 1 / wi;
-        double buffer[6];
-        for (int j = 0; j < 6; j++) buffer[j] = At[i][j] * wi;
-        for (int r = 0; r < 6; r++) {
-            const float sv = Vt[i][r];
-            for (int j = 0; j < 6; j++) Hinv[r * 6 + j] = (float)(Hinv[r * 6 + j] + sv * buffer[j]);
+        if (!(fabs(wi) <= threshold)) {
+            wi = 1 / wi;
+            double buffer[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) buffer[j] = At[i][j] * wi;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const float sv = Vt[i][r];
+#pragma unroll
+                for (int j = 0; j < 6; j++) Hinv[r * 6 + j] = (float)(Hinv[r * 6 + j] + sv * buffer[j]);
+            }
         }
     }
     const bool ok = W[0] >= FLT_EPSILON ? (W[5] / W[0] != 0) : false;
-    if (!ok)
+    if (!ok) {
+#pragma unroll
         for (int i = 0; i < 36; i++) Hinv[i] = 0;
+    }
 }
 
 // delta = pinv(H) b for the Gauss-Newton steps (pose_estimator.cpp:405,484;
@@ -395,8 +499,10 @@ __device__ inline void gn_solve6(const float H[36], const float b[6], float delt
     }
     float Hinv[36];
     inv_svd6(H, Hinv);
+#pragma unroll
     for (int r = 0; r < 6; r++) {
         float sacc = 0;
+#pragma unroll
         for (int c = 0; c < 6; c++) sacc += Hinv[r * 6 + c] * b[c];
         delta[r] = sacc;
     }

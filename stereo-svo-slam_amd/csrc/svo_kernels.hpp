@@ -37,17 +37,21 @@ struct SiaArgs {
     float* pose_out;              // [6]
     float* cost_out;              // [1]
     svo_gn_trace* trace;          // [SVO_MAX_PYRAMID_LEVELS] or null
-    float4* cache;                // workspace [cap*16]: per (kp,px) {gx, gy, ps_prev, i1_prev}
+    float* rec_ws;                // workspace [levels used][68][rec_cap]: per-level records of sia_prep_kernel
+    int rec_cap;                  // keypoint capacity (row length) of rec_ws, multiple of 4
+    float4* cache;                // workspace [cap*16]: per (kp,px) {gx, gy, ps_prev, i1_prev} (sia_big only)
     float* kp_ws;                 // workspace [(cap+16)*40] floats: per-keypoint arrays when they do not fit LDS
     float* dbg_H;                 // optional [36+6+6]: H, b, step of the first get_gradient of `dbg_level`
     int dbg_level;
     int cap;
-    int exact_pinv;               // 1: always the reference's SVD pseudo-inverse (slow, parity mode)
+    int exact_pinv;               // 1: reference-order normal equations + the reference's SVD pseudo-inverse (parity mode)
     PoseMats* mats_out;           // optional: rotation matrices of pose_out, for the kernels that project with it
 };
+// n_bound: upper bound of the keypoint counts of the launch's sequences (chooses the workgroup
+// shape); rec_cap: SiaArgs::rec_cap of every block; exact: the value of SiaArgs::exact_pinv in every block (sizes the LDS staging)
 void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
-                int height, int cap, hipStream_t stream);
-size_t sia_lds_bytes(const svo_camera_settings& cam, int width, int height, int n_bound);
+                int height, int n_bound, int rec_cap, int exact, hipStream_t stream);
+size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap);   // size of SiaArgs::rec_ws
 
 // --------------------------------------------------------------------- KLT
 struct KfDev {                    // one keyframe as the device sees it
@@ -59,6 +63,8 @@ struct KfDev {                    // one keyframe as the device sees it
     uint32_t* flags;              // ignore_temporary / ignore_completely mirror
     int* outlier_count;
     int* inlier_count;
+    // the rest of frame.kps.info as copied at creation (keyframe_manager.cpp:27): read by the getters only
+    int* kf_id; int* kp_index; float* score; int* level_type; uint32_t* color; float* kfx; float* kfP;
     int n;
 };
 

@@ -151,21 +151,32 @@ def _sia_inputs(sc, frame):
 
 
 @pytest.mark.parametrize("config,seed", [("tiny", 0), ("euroc", 0), ("euroc", 3), ("blender", 1)])
-def test_sia_first_gradient_matches(H, config, seed):
-    """H = sum J^T J, b and the GN step of the first get_gradient on the coarsest level."""
+@pytest.mark.parametrize("exact", [False, True])
+def test_sia_first_gradient_matches(H, config, seed, exact):
+    """H = sum J^T J, b and the GN step of the first get_gradient on the coarsest level.
+    Reference-order mode accumulates row by row like the reference (pose_estimator.cpp:399-403,
+    :472-477); the default mode sums J^T (sum g g^T) J per keypoint in a tree."""
     sc = util.scenario(config, 3, seed, 1)
     cfg = sc["cfg"]
     prev, cur, k2, k3, fl = _sia_inputs(sc, 1)
     level = cfg["max_pyramid_levels"] - 1
     guess = np.zeros(6, np.float32)
     Href, bref, sref = O.sia_gradient(prev[level], cur[level], level, k2, k3, fl, sc["cam"], guess)
-    H.set_exact_pinv(False)
+    H.set_exact_pinv(exact)
     gp = [dev(x) for x in prev]
     gc = [dev(x) for x in cur]
     _, _, _, dbg = H.sparse_align(gp, gc, dev(k2), dev(k3), dev(fl), cam_of(cfg), dev(guess),
                                   dbg_level=level)
+    H.set_exact_pinv(False)
     dbg = dbg.cpu().numpy()
     Hg, bg, sg = dbg[:36].reshape(6, 6), dbg[36:42], dbg[42:48]
+    if exact:
+        # same products added in the same order: equal up to the last bit of the double sin/cos
+        # behind the rotation matrix (device libm vs glibc)
+        assert np.allclose(Hg, Href, rtol=2e-6, atol=0), np.max(np.abs(Hg - Href) / (np.abs(Href) + 1e-30))
+        assert np.allclose(bg, bref, rtol=2e-6, atol=1e-6 * np.max(np.abs(bref)))
+        assert np.max(np.abs(sg - sref)) < 1e-5 * np.max(np.abs(sref)) + 1e-9
+        return
     scale = np.sqrt(np.outer(np.diag(Href), np.diag(Href))) + 1e-20
     assert np.max(np.abs(Hg - Href) / scale) < 2e-5      # float sums in a different order
     assert np.max(np.abs(bg - bref)) < 2e-5 * np.max(np.abs(bref)) + 1e-3
@@ -187,12 +198,18 @@ def test_sia_pose_matches_default_solver(H, config, seed, frame):
                                           dev(k3), dev(fl), cam_of(cfg), dev(guess))
     assert np.max(np.abs(pose.cpu().numpy() - pref)) < 1e-4, (pose, pref)
     assert abs(float(cost.cpu()) - cref) < 2e-3 * max(cref, 1.0) + 2.0
+    # the cost itself is summed in the reference's order in every mode: the first evaluation evaluation
+    # of the coarsest level (same pose, same images) has the oracle's bits
+    tr = hip_lib.trace_to_numpy(trace)
+    top = cfg["max_pyramid_levels"] - 1
+    assert tr[top]["initial_cost"] == tref[top]["initial_cost"]
 
 
 @pytest.mark.parametrize("config,seed,frame", [("tiny", 0, 1), ("tiny", 2, 1), ("euroc", 0, 1),
                                                ("euroc", 3, 1), ("blender", 1, 1), ("econ", 0, 1)])
 def test_sia_pose_matches(H, config, seed, frame):
-    """SVD route of the reference (svo_handle_set_exact_pinv): same iteration trace."""
+    """Reference-order mode (svo_handle_set_exact_pinv): row-by-row normal equations, Jacobi-SVD
+    pseudo-inverse, sequential cost sums: the reference's iteration trace, level by level."""
     H.set_exact_pinv(True)
     sc = util.scenario(config, 3, seed, 1)
     cfg = sc["cfg"]
@@ -203,13 +220,16 @@ def test_sia_pose_matches(H, config, seed, frame):
                                           dev(k3), dev(fl), cam_of(cfg), dev(guess))
     pose = pose.cpu().numpy()
     tr = hip_lib.trace_to_numpy(trace)
-    # tolerance of SURVEY §8d: 1e-4 m / 1e-4 rad
-    assert np.max(np.abs(pose - pref)) < 1e-4, (pose, pref)
-    assert abs(float(cost.cpu()) - cref) < 1e-3 * max(cref, 1.0) + 1.0
+    # SURVEY §8d states 1e-4 m / 1e-4 rad; with every sum in reference order the difference left is
+    # the last bit of the double sin/cos behind the rotation matrices
+    assert np.max(np.abs(pose - pref)) < 2e-6, (pose, pref)
+    assert abs(float(cost.cpu()) - cref) <= 1e-6 * max(cref, 1.0)
     for l in range(cfg["min_pyramid_level_pose_estimation"], cfg["max_pyramid_levels"]):
         assert tr[l]["n_gradient"] == tref[l]["n_gradient"], (l, tr[l], tref[l])
         assert tr[l]["n_cost"] == tref[l]["n_cost"], (l, tr[l], tref[l])
         assert tr[l]["n_accepted"] == tref[l]["n_accepted"]
+        assert tr[l]["exit_small"] == tref[l]["exit_small"]
+        assert abs(tr[l]["initial_cost"] - tref[l]["initial_cost"]) <= 1e-6 * max(tref[l]["initial_cost"], 1.0)
     H.set_exact_pinv(False)
 
 
@@ -228,9 +248,13 @@ def test_sia_no_valid_patch_is_a_clean_exit(H):
 
 
 # ------------------------------------------------------------------ B1 + B3
-@pytest.mark.parametrize("config,seed", [("tiny", 0), ("euroc", 0), ("econ", 2)])
-def test_reproj_gn_matches(H, config, seed):
-    sc = util.scenario(config, 3, seed, 1)
+@pytest.mark.parametrize("config,seed", [("tiny", 0), ("euroc", 0), ("euroc", 4), ("econ", 2), ("hd", 0)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_reproj_gn_matches(H, config, seed, exact):
+    """Cost and normal equations are summed in the reference's sequential order
+    (pose_refinement.cpp:328-341, :393-395) in both modes, so the line search that stops on
+    |dcost| < 1e-4 (:273) takes the oracle's path: the trace is asserted equal."""
+    sc = util.scenario(config, 2 if config == "hd" else 3, seed, 1)
     cfg = sc["cfg"]
     rng = np.random.RandomState(8)
     k3, fl = sc["kps3d"], util.flags_of(sc["info"]).copy()
@@ -246,16 +270,21 @@ def test_reproj_gn_matches(H, config, seed):
     k2_ref, fl_ref = O.refine_merge(proj, fl, tracked, err)
     pref, cref, tref = O.reproj_gn(k2_ref, k3, fl_ref, sc["cam"], start)
     k2_g, fl_g = dev(proj.copy()), dev(fl.copy())
+    H.set_exact_pinv(exact)
     pose, cost, trace = H.reproj_gn(k2_g, dev(k3), fl_g, cam_of(cfg), dev(start), dev(tracked), dev(err))
+    H.set_exact_pinv(False)
     assert np.array_equal(fl_g.cpu().numpy(), fl_ref)            # flags: bit exact
     assert np.array_equal(k2_g.cpu().numpy(), k2_ref)
-    assert np.max(np.abs(pose.cpu().numpy() - pref)) < 1e-4
+    assert np.max(np.abs(pose.cpu().numpy() - pref)) < (2e-6 if exact else 1e-4)
     tr = hip_lib.trace_to_numpy(trace)[0]
-    # the stop test |dcost| < 1e-4 (pose_refinement.cpp:273) sits at the rounding level of a
-    # float sum of ~100 terms, so the last line-search trial may differ by one or two evaluations
-    assert abs(int(tr["n_gradient"]) - tref["n_gradient"]) <= 3
-    assert abs(int(tr["n_cost"]) - tref["n_cost"]) <= 6
-    assert abs(float(cost.cpu()) - cref) < 1e-3
+    if exact:
+        assert int(tr["n_gradient"]) == tref["n_gradient"], (tr, tref)
+        assert int(tr["n_cost"]) == tref["n_cost"], (tr, tref)
+        assert int(tr["n_accepted"]) == tref["n_accepted"]
+    # (default mode: the LDL^T solve in double is not the reference's float SVD inverse, whose error in
+    # the weak directions of J^T J is large; the steps differ, the minimum within 1e-4 does not)
+    assert tr["initial_cost"] == tref["initial_cost"]            # same pose, sequential sum: same bits
+    assert abs(float(cost.cpu()) - cref) < (1e-5 if exact else 1e-3)
 
 
 # ------------------------------------------------------------------ C2 + D1

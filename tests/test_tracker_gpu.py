@@ -29,14 +29,33 @@ def _compare_frame(tag, gpu_frame, ok2, ok3, oinfo, pose_ref, tol=1e-4):
         assert np.max(np.abs(gpu_frame.kps3d - ok3)) < (2e-2 if loose else 5e-3), f"{tag}: kps3d"
 
 
-def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False, tol=1e-4):
-    cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device="cpu",
+def _same_trace(a, b, cfg):
+    """GN control flow of one frame: gradient / cost / accepted counts per alignment level and
+    of the reprojection GN, HIP (svo_frame_stats) against the oracle."""
+    pairs = [(a.sia_trace[lv], b.sia_trace[lv])
+             for lv in range(cfg["min_pyramid_level_pose_estimation"], cfg["max_pyramid_levels"])]
+    pairs.append((a.reproj_trace, b.reproj_trace))
+    return all((x.n_gradient, x.n_cost, x.n_accepted, x.exit_small) ==
+               (y.n_gradient, y.n_cost, y.n_accepted, y.exit_small) for x, y in pairs)
+
+
+def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False, tol=None,
+         render_device="cpu"):
+    """Both trackers frame by frame. exact (reference-order mode): every GN trace must equal the
+    oracle's and the pose bound is 1e-5; default mode: 1e-4. Returns the fraction of
+    tracked frames whose GN traces equal the oracle's as the third value."""
+    if tol is None:
+        tol = 1e-5 if exact else 1e-4
+    cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device=render_device,
                                                motion_scale=motion_scale)
+    L = [x.cpu() for x in L]
+    R = [x.cpu() for x in R]
     cam = util.oracle_camera(cfg)
     ref = O.Slam(cam)
     gpu = StereoSlam(cfg, cfg["width"], cfg["height"])
     gpu.set_exact_pinv(exact)
     n_kf = 0
+    same = 0
     for k in range(n_frames):
         l, r = L[k].numpy(), R[k].numpy()
         made = ref.new_image(l, r, float(ts[k]))
@@ -49,17 +68,24 @@ def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False,
         assert st.is_keyframe == made, f"frame {k}: keyframe decision"
         ok2, ok3, oinfo = ref.keypoints()
         _compare_frame(f"{config}/{seed} frame {k}", gpu.get_frame(), ok2, ok3, oinfo, ref.pose(), tol)
+        if k > 0:
+            eq = _same_trace(st, ref.stats(), cfg)
+            same += eq
+            # (1920x1080 runs the alignment from the HBM workspace, sia_big.hip: tree-order sums)
+            if exact and config != "hd":
+                assert eq, f"{config}/{seed} frame {k}: GN trace differs from the oracle's"
     assert gpu.num_keyframes() == ref.num_keyframes() == n_kf
     for kid in range(n_kf):
         k2, k3, info, pose = ref.keyframe(kid)
         g = gpu.get_keyframe(kid)
         assert np.array_equal(g.kps2d, k2) or np.max(np.abs(g.kps2d - k2)) < 5e-2
-        for f in ("ignore_completely", "ignore_temporary", "outlier_count", "inlier_count"):
+        for f in INT_FIELDS + ("color",):
             assert np.array_equal(g.info[f], info[f]), f"keyframe {kid} info.{f}"
+        assert np.array_equal(g.info["score"], info["score"]), f"keyframe {kid} score"
         assert np.max(np.abs(g.pose - pose)) < 1e-4
     traj = gpu.get_trajectory()
     assert traj.shape == (n_frames, 6)
-    return gpu, ref
+    return gpu, ref, same / max(n_frames - 1, 1)
 
 
 def test_first_frame_keyframe_bit_exact():
@@ -106,20 +132,35 @@ def test_sequence_matches_oracle(config, n_frames, seed, exact):
 
 def test_sequence_with_keyframe_creation():
     """Fast motion so that keyframe_needed fires inside the sequence."""
-    gpu, ref = _run("tiny", 30, 1, motion_scale=4.0)
+    gpu, ref, _ = _run("tiny", 30, 1, motion_scale=4.0)
     assert ref.num_keyframes() >= 2
 
 
-def test_long_sequence_with_keyframes_at_full_size():
+@pytest.mark.parametrize("exact", [False, True])
+def test_long_sequence_with_keyframes_at_full_size(exact):
     """Stress case: 60 frames of the C2 configuration at 3x the motion, several keyframes inside the
-    sequence. Feature index lists, flags and counters stay bit-exact on every frame. The pose bound is
-    looser here than the 1e-4 of the other sequences: both Gauss-Newton loops stop on cost changes at
-    float32 resolution (cost ~6000), so a different summation order changes iteration counts now
-    and then (tools/parity_trace.py: e.g. 14 vs 12 alignment steps at frame 38), the poses drift
-    apart by up to ~1e-3 for a few frames and re-converge (1.5e-5 again five frames later)."""
-    gpu, ref = _run("euroc", 60, 5, motion_scale=3.0, tol=3e-3)
+    sequence. Feature index lists, flags and counters bit-exact on every frame, pose within the
+    stated 1e-4 in both modes; in reference-order mode every GN trace equals the oracle's."""
+    gpu, ref, same = _run("euroc", 60, 5, motion_scale=3.0, exact=exact, render_device="cuda")
     assert ref.num_keyframes() >= 3
-    assert np.max(np.abs(gpu.get_frame().pose - ref.pose())) < 5e-4
+    assert np.max(np.abs(gpu.get_frame().pose - ref.pose())) < (1e-5 if exact else 1e-4)
+    print(f"stress sequence, exact={exact}: {same:.3f} of the frames with the oracle's GN trace")
+
+
+def test_drift_over_300_frames():
+    """trajectory drift against the restatement over 300 frames of the C2
+    configuration <= 1 mm / 0.01 deg, identical accept / reject trace on >= 99 % of the frames
+    (default mode; reference-order mode: on every frame, asserted inside _run)."""
+    n = 300
+    for exact in (True, False):
+        gpu, ref, same = _run("euroc", n, 7, exact=exact, render_device="cuda")
+        d = np.abs(gpu.get_trajectory() - np.array([ref.pose()]))[-1]
+        drift_t, drift_r = float(np.max(d[:3])), float(np.max(d[3:]))
+        print(f"300 frames, exact={exact}: drift {drift_t * 1e3:.4f} mm / {np.degrees(drift_r):.5f} deg, "
+              f"{same:.4f} of the frames with the oracle's GN trace, {ref.num_keyframes()} keyframes")
+        assert drift_t <= 1e-3 and drift_r <= np.radians(0.01)
+        assert same >= 0.99
+        gpu.close()
 
 
 def test_device_resident_input():
