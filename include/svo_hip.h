@@ -16,6 +16,8 @@
 #ifndef SVO_HIP_H
 #define SVO_HIP_H
 
+#include <stddef.h>
+
 #include "svo_types.h"
 
 #ifdef __cplusplus
@@ -40,12 +42,28 @@ int svo_handle_create(int device, int max_keypoints, svo_handle **out);
 int svo_handle_destroy(svo_handle *h);
 int svo_handle_set_stream(svo_handle *h, void *hip_stream); /* hipStream_t, NULL = default */
 int svo_handle_synchronize(svo_handle *h);
-/* The Gauss-Newton steps need pinv(J^T J) b (Matx66f::inv(DECOMP_SVD),
- * src/lib/pose_estimator.cpp:405, pose_refinement.cpp:398). Default (0): a
- * positive definite 6x6 system is solved by LDL^T in double and only rank
- * deficient ones take the reference's Jacobi-SVD route; 1: always the SVD
- * route (slower; reproduces the reference's iteration trace). */
-int svo_handle_set_exact_pinv(svo_handle *h, int on);
+/* The two Gauss-Newton kernels (sparse alignment, reprojection) have two forms of the normal
+ * equations. Default (fast_solver = 0): the reference's arithmetic — `hessian += row^T row`,
+ * `residual -= row * diff` accumulated row by row in storage order and the Jacobi-SVD
+ * pseudo-inverse of Matx66f::inv(DECOMP_SVD) (src/lib/pose_estimator.cpp:399-405,472-477,
+ * pose_refinement.cpp:393-398): poses, costs and iteration traces are the CPU restatement's, bit
+ * for bit. fast_solver = 1: J^T (sum g g^T) J per keypoint summed in a tree and an LDL^T solve in
+ * double (SVD only for rank deficient systems): ~1.5x the frame rate, same minimum within
+ * 1e-4 m / rad on smooth motion, but not the reference's iteration trace.
+ * (The cost is summed in the reference's order in both.) */
+int svo_handle_set_fast_solver(svo_handle *h, int on);
+int svo_handle_set_exact_pinv(svo_handle *h, int on);   /* older name: set_fast_solver(!on) */
+
+/* device memory for callers without a HIP toolchain (the C++ facades in
+ * stereo-svo-slam_amd/hostcpp/, ctypes): plain hipMalloc / hipFree and copies that are
+ * ordered on the handle's stream and complete on return */
+int svo_device_malloc(size_t bytes, void **out);
+int svo_device_free(void *p);
+int svo_copy_to_device(svo_handle *h, void *dst, const void *src, size_t bytes);
+int svo_copy_to_host(svo_handle *h, void *dst, const void *src, size_t bytes);
+/* rows of `width` bytes: host image (src_stride) -> device image (dst_stride) */
+int svo_copy_image_to_device(svo_handle *h, void *dst, size_t dst_stride, const void *src,
+                             size_t src_stride, size_t width, size_t height);
 
 /* ---- stage level entry points (one per row of SURVEY §8a) ----------------
  * P1  createImgPyramid / halfSample          src/lib/stereo_slam.cpp:93-121
@@ -67,6 +85,12 @@ int svo_sparse_align(svo_handle *h, const svo_image *prev_pyr, const svo_image *
                      const svo_kp2d *kps2d, const svo_kp3d *kps3d, const uint32_t *flags, int n,
                      const svo_camera_settings *cam, const float *pose_guess, float *pose_out,
                      float *cost, svo_gn_trace *trace, float *dbg, int dbg_level);
+
+/* A3  project_keypoints(pose, in, camera_settings, out)   src/include/transform_keypoints.hpp:17-19,
+ *                                              src/lib/transform_keypoints.cpp:11-48
+ * pose: 6 floats in device memory. */
+int svo_project_keypoints(svo_handle *h, const float *pose, const svo_kp3d *kps3d, int n,
+                          const svo_camera_settings *cam, svo_kp2d *out);
 
 /* B2  OpticalFlow::calculate_optical_flow      src/include/optical_flow.hpp:26-30,
  *                                              src/lib/optical_flow.cpp:14-56 */
@@ -119,7 +143,9 @@ int svo_ctx_destroy(svo_ctx *ctx);
  * for every sequence of the ctx: left[s]/right[s] point to 8-bit images of the
  * ctx size with `stride` bytes per row, in host (SVO_MEM_HOST) or device memory.
  * The images are copied; the caller may reuse its buffers on return. Returns
- * after the frame is complete (like the reference). */
+ * after the frame is complete (like the reference). A sequence whose two pointers are
+ * NULL sits the step out with its state untouched (sequences of one ctx may have different
+ * lengths); the very first step needs every sequence. */
 int svo_new_images(svo_ctx *ctx, const uint8_t *const *left, const uint8_t *const *right,
                    int stride, const float *time_stamps, int mem);
 /* Pipelined form (no counterpart in the reference, whose new_image is synchronous): svo_submit_images() queues one frame set (same arguments; the images,
@@ -188,7 +214,8 @@ typedef struct svo_totals {
 } svo_totals;
 int svo_get_totals(svo_ctx *ctx, svo_totals *out);
 int svo_ctx_enable_timing(svo_ctx *ctx, int on);
-int svo_ctx_set_exact_pinv(svo_ctx *ctx, int on);   /* see svo_handle_set_exact_pinv */
+int svo_ctx_set_fast_solver(svo_ctx *ctx, int on);  /* see svo_handle_set_fast_solver; default 0 */
+int svo_ctx_set_exact_pinv(svo_ctx *ctx, int on);   /* older name: set_fast_solver(!on) */
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ namespace svo {
 // past the end of the image row
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ inline uint32_t load_u8x4(const ImgView& im, int y, int x, int valid) {
-    const uint8_t* src = im.data + (size_t)y * im.stride + x;
+    const uint8_t* src = im.g() + (size_t)y * im.stride + x;
     uint32_t v;
     if (x + 4 <= im.w) {
         v = *reinterpret_cast<const u32_unaligned*>(src);
@@ -66,9 +66,9 @@ typedef int ssd_v4i __attribute__((ext_vector_type(4)));
 //  * argmin (first minimum in row-major order) and the tie-averaged column of :313-323 as before.
 __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
     const SsdArgs& a = args[blockIdx.y];
-    if (a.enable && !*a.enable) return;
-    const int n = *a.n_ptr;
-    const int kp = a.first + (a.first_ptr ? *a.first_ptr : 0) + (int)blockIdx.x;
+    if (a.enable && !*G(a.enable)) return;
+    const int n = *G(a.n_ptr);
+    const int kp = a.first + (a.first_ptr ? *G(a.first_ptr) : 0) + (int)blockIdx.x;
     if (kp >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
 
     const int window_before = a.win / 2, window_after = (a.win + 1) / 2;
     const int cols = a.left.w, rows = a.left.h;
-    const svo_kp2d p = a.kps2d[kp];
+    const svo_kp2d p = G(a.kps2d)[kp];
     const int x = (int)p.x, y = (int)p.y;
     const int x11 = max(0, x - window_before);
     const int x12 = min(cols - 1, x + window_after);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
         rh > SSD_R_ROWS)
         skip = true;  // the host validates window sizes; never taken with valid settings
     if (skip) {
-        if (tid == 0) a.disparity[kp] = -1.0f;
+        if (tid == 0) G(a.disparity)[kp] = -1.0f;
         return;
     }
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
         for (int w = 0; w < SSD_THREADS / 64; w++) { ts += s_sum[w]; tc += s_cnt[w]; }
         float minPos = (float)ts;      // sum of small ints: exact in float in any order
         minPos = minPos / tc;
-        a.disparity[kp] = a.clamp_half ? fmaxf(0.5f, minPos) : minPos;
+        G(a.disparity)[kp] = a.clamp_half ? fmaxf(0.5f, minPos) : minPos;
     }
 }
 
@@ -271,13 +271,13 @@ void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream)
 // -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __restrict__ args) {
     const FilterArgs& a = args[blockIdx.x];
-    const int n = *a.n_ptr;
+    const int n = *G(a.n_ptr);
     const int tid = threadIdx.x;
     __shared__ PoseMats s_frame;
     __shared__ int s_inside[4];
     if (tid == 0) {
         float pose[6];
-        for (int i = 0; i < 6; i++) pose[i] = a.frame_pose[i];
+        for (int i = 0; i < 6; i++) pose[i] = G(a.frame_pose)[i];
         pose_mats(pose, s_frame);
     }
     __syncthreads();
@@ -290,27 +290,29 @@ __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __
         float kfp[6];
         svo_kp3d r3;
         svo_kp2d r2;
-        KfDev* kf = nullptr;
+        SVO_GP(KfDev) kf = nullptr;
         int kidx = 0;
         if (a.kfs) {
-            kf = &a.kfs[a.kf_id[i]];
-            kidx = a.kp_index[i];
+            kf = &G(a.kfs)[G(a.kf_id)[i]];
+            kidx = G(a.kp_index)[i];
             for (int q = 0; q < 6; q++) kfp[q] = kf->pose[q];
-            r3 = kf->kps3d[kidx];
-            r2 = kf->kps2d[kidx];
+            r3 = G(kf->kps3d)[kidx];
+            r2 = G(kf->kps2d)[kidx];
         } else {
-            for (int q = 0; q < 6; q++) kfp[q] = a.kf_pose[(size_t)i * 6 + q];
-            r3 = a.ref3d ? a.ref3d[i] : svo_kp3d{0, 0, 0};
-            r2 = a.ref2d ? a.ref2d[i] : svo_kp2d{0, 0};
+            for (int q = 0; q < 6; q++) kfp[q] = G(a.kf_pose)[(size_t)i * 6 + q];
+            r3 = svo_kp3d{0, 0, 0};
+            r2 = svo_kp2d{0, 0};
+            if (a.ref3d) r3 = G(a.ref3d)[i];
+            if (a.ref2d) r2 = G(a.ref2d)[i];
         }
         PoseMats km;
         pose_mats(kfp, km);
-        const svo_kp2d kp2 = a.kps2d[i];
-        uint32_t flags = a.flags[i];
-        int outl = a.outlier_count[i], inl = a.inlier_count[i];
+        const svo_kp2d kp2 = G(a.kps2d)[i];
+        uint32_t flags = G(a.flags)[i];
+        int outl = G(a.outlier_count)[i], inl = G(a.inlier_count)[i];
 
         if (a.do_outlier_check) {   // depth_filter.cpp:52-128
-            const float d = a.disparity[i];
+            const float d = G(a.disparity)[i];
             const float _z = baseline / fmaxf(d, 0.5f);
             const float _x = (kp2.x - cx) / fx * _z;
             const float _y = (kp2.y - cy) / fy * _z;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __
             else inl++;
         }
 
-        svo_kp3d p3 = a.kps3d[i];
+        svo_kp3d p3 = G(a.kps3d)[i];
         if (a.do_update) {          // depth_filter.cpp:130-257
             const float c1[3] = {kfp[0], kfp[1], kfp[2]};
             const float c2[3] = {s_frame.t[0], s_frame.t[1], s_frame.t[2]};
@@ -355,10 +357,10 @@ __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __
                 float new_p[3];
                 mat33f_vec(Mx, pc, new_p);
                 float _z = new_p[2];
-                float kx = a.kf_inv_depth[i], kP = a.kf_variance[i];
+                float kx = G(a.kf_inv_depth)[i], kP = G(a.kf_variance)[i];
                 kf1_update(kx, kP, 0.0001f, Rm, 1 / _z);
-                a.kf_inv_depth[i] = kx;
-                a.kf_variance[i] = kP;
+                G(a.kf_inv_depth)[i] = kx;
+                G(a.kf_variance)[i] = kP;
                 _z = (float)(1.0 / (double)kx);
                 const float _x = (r2.x - cx) / fx * _z;
                 const float _y = (r2.y - cy) / fy * _z;
@@ -374,21 +376,21 @@ __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __
             if (outl > inl) flags |= SVO_IGNORE_COMPLETELY;
             if (inl > outl) flags &= ~(uint32_t)SVO_IGNORE_TEMPORARY;
             if (kf) {
-                kf->kps3d[kidx] = p3;
-                const uint32_t keep = kf->flags[kidx] & SVO_IGNORE_DURING_REFINEMENT;
-                kf->flags[kidx] = keep | (flags & (SVO_IGNORE_TEMPORARY | SVO_IGNORE_COMPLETELY));
-                kf->inlier_count[kidx] = inl;
-                kf->outlier_count[kidx] = outl;
+                G(kf->kps3d)[kidx] = p3;
+                const uint32_t keep = G(kf->flags)[kidx] & SVO_IGNORE_DURING_REFINEMENT;
+                G(kf->flags)[kidx] = keep | (flags & (SVO_IGNORE_TEMPORARY | SVO_IGNORE_COMPLETELY));
+                G(kf->inlier_count)[kidx] = inl;
+                G(kf->outlier_count)[kidx] = outl;
             }
         }
-        a.kps3d[i] = p3;
-        if (a.do_flags) a.flags[i] = flags;
-        a.outlier_count[i] = outl;
-        a.inlier_count[i] = inl;
+        G(a.kps3d)[i] = p3;
+        if (a.do_flags) G(a.flags)[i] = flags;
+        G(a.outlier_count)[i] = outl;
+        G(a.inlier_count)[i] = inl;
 
         if (a.do_reproject) {       // stereo_slam.cpp:228-229 + keyframe_manager.cpp:55-64
             const svo_kp2d q = project_point(s_frame.Rd, s_frame.t, camd, p3);
-            a.kps2d[i] = q;
+            G(a.kps2d)[i] = q;
             if (q.x > 0 && q.y > 0 && q.x < a.width && q.y < a.height && !(flags & SVO_IGNORE_COMPLETELY))
                 inside++;
         }
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256) void filter_update_kernel(const FilterArgs* __
         inside = wave_sum_i(inside);
         if ((tid & 63) == 0) s_inside[tid >> 6] = inside;
         __syncthreads();
-        if (tid == 0) *a.inside_count = s_inside[0] + s_inside[1] + s_inside[2] + s_inside[3];
+        if (tid == 0) *G(a.inside_count) = s_inside[0] + s_inside[1] + s_inside[2] + s_inside[3];
     }
 }
 

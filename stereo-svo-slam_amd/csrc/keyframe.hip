@@ -46,36 +46,36 @@ __device__ inline int block_exclusive_scan(int v, int* s_wave /*[16]*/, int& tot
 }
 
 __device__ inline void copy_kp(const KpsDev& d, int di, const KpsDev& s, int si) {
-    d.kps2d[di] = s.kps2d[si];
-    d.kps3d[di] = s.kps3d[si];
-    d.flags[di] = s.flags[si];
-    d.kf_id[di] = s.kf_id[si];
-    d.kp_index[di] = s.kp_index[si];
-    d.outl[di] = s.outl[si];
-    d.inl[di] = s.inl[si];
-    d.kfx[di] = s.kfx[si];
-    d.kfP[di] = s.kfP[si];
-    d.score[di] = s.score[si];
-    d.level_type[di] = s.level_type[si];
-    d.color[di] = s.color[si];
+    G(d.kps2d)[di] = G(s.kps2d)[si];
+    G(d.kps3d)[di] = G(s.kps3d)[si];
+    G(d.flags)[di] = G(s.flags)[si];
+    G(d.kf_id)[di] = G(s.kf_id)[si];
+    G(d.kp_index)[di] = G(s.kp_index)[si];
+    G(d.outl)[di] = G(s.outl)[si];
+    G(d.inl)[di] = G(s.inl)[si];
+    G(d.kfx)[di] = G(s.kfx)[si];
+    G(d.kfP)[di] = G(s.kfP)[si];
+    G(d.score)[di] = G(s.score)[si];
+    G(d.level_type)[di] = G(s.level_type)[si];
+    G(d.color)[di] = G(s.color)[si];
 }
 
 __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __restrict__ args) {
     const CompactArgs& a = args[blockIdx.x];
-    if (a.enable && !*a.enable) return;
+    if (a.enable && !*G(a.enable)) return;
     __shared__ int s_wave[16];
     const int tid = threadIdx.x;
-    const int n = *a.src.n;
+    const int n = *G(a.src.n);
     const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
     const int i0 = tid * per, i1 = min(n, i0 + per);
     int cnt = 0;
     for (int i = i0; i < i1; i++) {
-        const uint32_t f = a.src.flags[i];
+        const uint32_t f = G(a.src.flags)[i];
         bool keep;
         if (a.mode == 0) {
             keep = !(f & SVO_IGNORE_COMPLETELY);
         } else {
-            const svo_kp2d k = a.src.kps2d[i];
+            const svo_kp2d k = G(a.src.kps2d)[i];
             keep = !((k.x < 0) || (k.y < 0) || (k.x > a.width) || (k.y > a.height) ||
                      (f & SVO_IGNORE_COMPLETELY) || (f & SVO_IGNORE_DURING_REFINEMENT));
         }
@@ -84,18 +84,18 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
     int total;
     int pos = block_exclusive_scan(cnt, s_wave, total);
     for (int i = i0; i < i1; i++) {
-        const uint32_t f = a.src.flags[i];
+        const uint32_t f = G(a.src.flags)[i];
         bool keep;
         if (a.mode == 0) {
             keep = !(f & SVO_IGNORE_COMPLETELY);
         } else {
-            const svo_kp2d k = a.src.kps2d[i];
+            const svo_kp2d k = G(a.src.kps2d)[i];
             keep = !((k.x < 0) || (k.y < 0) || (k.x > a.width) || (k.y > a.height) ||
                      (f & SVO_IGNORE_COMPLETELY) || (f & SVO_IGNORE_DURING_REFINEMENT));
         }
         if (keep) copy_kp(a.dst, pos++, a.src, i);
     }
-    if (tid == 0) *a.dst.n = total;
+    if (tid == 0) *G(a.dst.n) = total;
 }
 
 // Small sets run with 256 threads: a 16-wave workgroup only starts on a CU that has drained, and
@@ -154,7 +154,7 @@ __device__ inline int fast_score(const uint8_t* p, int stride, int threshold) {
 
 __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __restrict__ args) {
     const DetectArgs& a = args[blockIdx.z];
-    if (a.enable && !*a.enable) return;
+    if (a.enable && !*G(a.enable)) return;
     const int level = blockIdx.y;
     if (level >= a.n_levels) return;
     const ImgView im = a.level[level];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     for (int i = tid; i < tw * th; i += 256) {
         const int r = i / tw, c = i % tw;
         const int gy = reflect101(top - 4 + r, im.h), gx = reflect101(left - 4 + c, im.w);
-        s_t[r * DET_TW + c] = im.data[(size_t)gy * im.stride + gx];
+        s_t[r * DET_TW + c] = im.g()[(size_t)gy * im.stride + gx];
     }
     __syncthreads();
     // raw FAST scores on the cell + 1 px (0 outside the detector's 3 px border)
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     if (tid == 0) {
         DetCell o;
         o.x = px; o.y = py; o.score = score; o.type = type;
-        a.out[(size_t)level * a.max_cells + cell] = o;
-        if (cell == 0) a.n_out[level] = ncx * ncy;
+        G(a.out)[(size_t)level * a.max_cells + cell] = o;
+        if (cell == 0) G(a.n_out)[level] = ncx * ncy;
     }
 }
 
@@ -254,21 +254,21 @@ void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_lev
 // --------------------------------------------------------- select + merge
 __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* __restrict__ args) {
     const MergeArgs& a = args[blockIdx.x];
-    if (a.enable && !*a.enable) return;
+    if (a.enable && !*G(a.enable)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int nsel = a.n_det[0];
-    const int n_old = *a.kps.n;
+    const int nsel = G(a.n_det)[0];
+    const int n_old = *G(a.kps.n);
     const int mcw = a.cam.grid_height, mch = a.cam.grid_width;   // swapped on purpose (:179-180)
     const int ncx = (a.width + mcw - 1) / mcw, ncy = (a.height + mch - 1) / mch;
     const int ncells = ncx * ncy;
 
     // select_best_keypoints: entry j of level i is compared with entry j of level 0
     for (int j = tid; j < nsel; j += nthr) {
-        DetCell s = a.det[j];
+        DetCell s = G(a.det)[j];
         int lvl = 0;
         for (int i = 1; i < a.n_levels; i++) {
-            if (j >= a.n_det[i]) continue;   // the reference would read out of bounds
-            const DetCell c = a.det[(size_t)i * a.max_cells + j];
+            if (j >= G(a.n_det)[i]) continue;   // the reference would read out of bounds
+            const DetCell c = G(a.det)[(size_t)i * a.max_cells + j];
             if (s.type == SVO_KP_FAST && c.type == SVO_KP_EDGELET) continue;
             if (s.type == c.type && s.score > c.score) continue;
             s = c;
@@ -276,30 +276,30 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
             s.y *= (float)(1 << i);
             lvl = i;
         }
-        a.sel[j] = s;
-        a.sel_level[j] = lvl;
-        a.sel_cell[j] = -1;
+        G(a.sel)[j] = s;
+        G(a.sel_level)[j] = lvl;
+        G(a.sel_cell)[j] = -1;
     }
-    for (int c = tid; c < ncells; c += nthr) a.occupied[c] = 0;
+    for (int c = tid; c < ncells; c += nthr) G(a.occupied)[c] = 0;
     __syncthreads();
     // cells that already hold a keypoint (strictly inside)
     for (int i = tid; i < n_old; i += nthr) {
-        const svo_kp2d k = a.kps.kps2d[i];
+        const svo_kp2d k = G(a.kps.kps2d)[i];
         if (!(k.x > 0 && k.y > 0)) continue;
         const int xi = (int)floorf(k.x) / mcw, yi = (int)floorf(k.y) / mch;
         if (xi >= ncx || yi >= ncy) continue;
         const int l = xi * mcw, t = yi * mch;
-        if (k.x > l && k.x < l + mcw && k.y > t && k.y < t + mch) a.occupied[xi * ncy + yi] = 1;
+        if (k.x > l && k.x < l + mcw && k.y > t && k.y < t + mch) G(a.occupied)[xi * ncy + yi] = 1;
     }
     __syncthreads();
     for (int j = tid; j < nsel; j += nthr) {
-        const DetCell s = a.sel[j];
+        const DetCell s = G(a.sel)[j];
         if (!(s.x > 0 && s.y > 0)) continue;
         const int xi = (int)floorf(s.x) / mcw, yi = (int)floorf(s.y) / mch;
         if (xi >= ncx || yi >= ncy) continue;
         const int l = xi * mcw, t = yi * mch;
-        if (s.x > l && s.x < l + mcw && s.y > t && s.y < t + mch && !a.occupied[xi * ncy + yi])
-            a.sel_cell[j] = xi * ncy + yi;
+        if (s.x > l && s.x < l + mcw && s.y > t && s.y < t + mch && !G(a.occupied)[xi * ncy + yi])
+            G(a.sel_cell)[j] = xi * ncy + yi;
     }
     __syncthreads();
     // output order of the reference: cells x-outer / y-inner, candidates by index
@@ -307,28 +307,28 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     for (int j = tid; j < nsel; j += nthr) {
-        const int cj = a.sel_cell[j];
+        const int cj = G(a.sel_cell)[j];
         if (cj < 0) continue;
         int pos = 0;
         for (int q = 0; q < nsel; q++) {
-            const int cq = a.sel_cell[q];
+            const int cq = G(a.sel_cell)[q];
             pos += (cq >= 0 && (cq < cj || (cq == cj && q < j))) ? 1 : 0;
         }
         atomicAdd(&s_cnt, 1);
         const int di = n_old + pos;
         if (di < a.cap) {
-            const DetCell s = a.sel[j];
-            a.kps.kps2d[di] = svo_kp2d{s.x, s.y};
-            a.kps.score[di] = s.score;
-            a.kps.level_type[di] = a.sel_level[j] | (s.type << 8);
+            const DetCell s = G(a.sel)[j];
+            G(a.kps.kps2d)[di] = svo_kp2d{s.x, s.y};
+            G(a.kps.score)[di] = s.score;
+            G(a.kps.level_type)[di] = G(a.sel_level)[j] | (s.type << 8);
         }
     }
     __syncthreads();
     if (tid == 0) {
         int n_new = s_cnt;
-        if (n_old + n_new > a.cap) { n_new = a.cap - n_old; *a.overflow = 1; }
-        *a.old_count = n_old;
-        *a.kps.n = n_old + n_new;
+        if (n_old + n_new > a.cap) { n_new = a.cap - n_old; *G(a.overflow) = 1; }
+        *G(a.old_count) = n_old;
+        *G(a.kps.n) = n_old + n_new;
     }
 }
 
@@ -339,56 +339,56 @@ void launch_select_merge(const MergeArgs* d_args, int batch, int max_cells, hipS
 // ------------------------------------------------------------------- init
 __global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restrict__ args) {
     const KfInitArgs& a = args[blockIdx.x];
-    if (a.enable && !*a.enable) return;
+    if (a.enable && !*G(a.enable)) return;
     const int tid = threadIdx.x;
-    const int n = *a.kps.n, old_count = *a.old_count;
+    const int n = *G(a.kps.n), old_count = *G(a.old_count);
     __shared__ PoseMats pm;
     __shared__ int s_cnt[4];
     float pose[6];
-    for (int i = 0; i < 6; i++) pose[i] = a.first_frame ? 0.f : a.frame_pose[i];
+    for (int i = 0; i < 6; i++) pose[i] = a.first_frame ? 0.f : G(a.frame_pose)[i];
     if (tid == 0) pose_mats(pose, pm);
     __syncthreads();
     const float fx = a.cam.fx, fy = a.cam.fy, cx = a.cam.cx, cy = a.cam.cy, baseline = a.cam.baseline;
-    const uint32_t lcg0 = *a.color_lcg;
+    const uint32_t lcg0 = *G(a.color_lcg);
     for (int i = old_count + tid; i < n; i += 256) {
-        const svo_kp2d kp = a.kps.kps2d[i];
-        const float disparity = a.disparity[i];
+        const svo_kp2d kp = G(a.kps.kps2d)[i];
+        const float disparity = G(a.disparity)[i];
         const float _z = baseline / fmaxf(0.5f, disparity);
         const float _x = (kp.x - cx) / fx * _z;
         const float _y = (kp.y - cy) / fy * _z;
         float loc[3] = {_x, _y, _z};
         mat33f_vec(pm.R, loc, loc);
-        a.kps.kps3d[i] = svo_kp3d{loc[0] + pm.t[0], loc[1] + pm.t[1], loc[2] + pm.t[2]};
+        G(a.kps.kps3d)[i] = svo_kp3d{loc[0] + pm.t[0], loc[1] + pm.t[1], loc[2] + pm.t[2]};
         uint32_t st = lcg0;
         for (int q = old_count; q <= i; q++) st = st * 1664525u + 1013904223u;
-        a.kps.color[i] = (st >> 8) & 0xFFFFFFu;
-        a.kps.kf_id[i] = a.new_kf_id;
-        a.kps.kp_index[i] = i;
-        a.kps.flags[i] = SVO_IGNORE_TEMPORARY;
-        a.kps.inl[i] = 0;
-        a.kps.outl[i] = 0;
+        G(a.kps.color)[i] = (st >> 8) & 0xFFFFFFu;
+        G(a.kps.kf_id)[i] = a.new_kf_id;
+        G(a.kps.kp_index)[i] = i;
+        G(a.kps.flags)[i] = SVO_IGNORE_TEMPORARY;
+        G(a.kps.inl)[i] = 0;
+        G(a.kps.outl)[i] = 0;
         const float deviation = (float)(0.5 / (double)(baseline / fx));
-        a.kps.kfP[i] = deviation * deviation;
-        a.kps.kfx[i] = 1 / _z;
+        G(a.kps.kfP)[i] = deviation * deviation;
+        G(a.kps.kfx)[i] = 1 / _z;
     }
     __syncthreads();
     // keyframe.kps = frame.kps; keyframe.pose = frame.pose (keyframe_manager.cpp:27-29)
-    KfDev& kf = a.kfs[a.new_kf_id];
+    const KfDev kf = G(a.kfs)[a.new_kf_id];   // the pointers of the record (scalar loads)
     int not_temp = 0;
     for (int i = tid; i < n; i += 256) {
-        const uint32_t f = a.kps.flags[i];
-        kf.kps2d[i] = a.kps.kps2d[i];
-        kf.kps3d[i] = a.kps.kps3d[i];
-        kf.flags[i] = f;
-        kf.outlier_count[i] = a.kps.outl[i];
-        kf.inlier_count[i] = a.kps.inl[i];
-        kf.kf_id[i] = a.kps.kf_id[i];
-        kf.kp_index[i] = a.kps.kp_index[i];
-        kf.score[i] = a.kps.score[i];
-        kf.level_type[i] = a.kps.level_type[i];
-        kf.color[i] = a.kps.color[i];
-        kf.kfx[i] = a.kps.kfx[i];
-        kf.kfP[i] = a.kps.kfP[i];
+        const uint32_t f = G(a.kps.flags)[i];
+        G(kf.kps2d)[i] = G(a.kps.kps2d)[i];
+        G(kf.kps3d)[i] = G(a.kps.kps3d)[i];
+        G(kf.flags)[i] = f;
+        G(kf.outlier_count)[i] = G(a.kps.outl)[i];
+        G(kf.inlier_count)[i] = G(a.kps.inl)[i];
+        G(kf.kf_id)[i] = G(a.kps.kf_id)[i];
+        G(kf.kp_index)[i] = G(a.kps.kp_index)[i];
+        G(kf.score)[i] = G(a.kps.score)[i];
+        G(kf.level_type)[i] = G(a.kps.level_type)[i];
+        G(kf.color)[i] = G(a.kps.color)[i];
+        G(kf.kfx)[i] = G(a.kps.kfx)[i];
+        G(kf.kfP)[i] = G(a.kps.kfP)[i];
         not_temp += (f & SVO_IGNORE_TEMPORARY) ? 0 : 1;
     }
     not_temp = wave_sum_i(not_temp);
@@ -396,17 +396,18 @@ __global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restri
     __syncthreads();
     not_temp = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (tid == 0) {
-        kf.n = n;
-        for (int i = 0; i < 6; i++) kf.pose[i] = pose[i];
+        SVO_GP(KfDev) kfw = G(a.kfs) + a.new_kf_id;
+        kfw->n = n;
+        for (int i = 0; i < 6; i++) kfw->pose[i] = pose[i];
         uint32_t st = lcg0;
         for (int q = old_count; q < n; q++) st = st * 1664525u + 1013904223u;
-        *a.color_lcg = st;
-        *a.n_out = n;
+        *G(a.color_lcg) = st;
+        *G(a.n_out) = n;
     }
     // stereo_slam.cpp:157-159 (first frame) and :237-245 (too few usable points)
     const bool clear_all = a.first_frame || ((size_t)not_temp < (size_t)n / 4);
     if (clear_all)
-        for (int i = tid; i < n; i += 256) a.kps.flags[i] &= ~(uint32_t)SVO_IGNORE_TEMPORARY;
+        for (int i = tid; i < n; i += 256) G(a.kps.flags)[i] &= ~(uint32_t)SVO_IGNORE_TEMPORARY;
 }
 
 void launch_kf_init(const KfInitArgs* d_args, int batch, hipStream_t stream) {

@@ -140,7 +140,7 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
         constexpr int NP = (MAXROWS + RPP - 1) / RPP;
         const int c4 = tid & 15, r0 = tid >> 4;
         if (c4 < nq) {
-            const uint8_t* g = im.data + M24(y0 + r0, im.stride) + x0 + 4 * c4;
+            const uint8_t* g = im.g() + M24(y0 + r0, im.stride) + x0 + 4 * c4;
             uint32_t v[NP];
 #pragma unroll
             for (int u = 0; u < NP; u++)
@@ -158,7 +158,7 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int gy = reflect101(y0 + min(r + u, rows - 1), im.h);
-                    v[u] = im.data[M24(gy, im.stride) + gx];            // offsets < 2^31
+                    v[u] = im.g()[M24(gy, im.stride) + gx];            // offsets < 2^31
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     constexpr int RPT = (((ROWS + NG - 1) / NG) + 1) & ~1;              // even: rows are kept as pairs
     constexpr int NPAIR = RPT / 2;
     const KltArgs& a = args[blockIdx.y];
-    const int n = *a.n_ptr;
+    const int n = *G(a.n_ptr);
     const int kp = blockIdx.x;
     if (kp >= n) return;
     const int tid = threadIdx.x;
@@ -192,8 +192,9 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     __shared__ __attribute__((aligned(16))) uint8_t s_J[KLT_TJROWS * KLT_TJS];
     __shared__ long long s_part[KLT_WAVES][4];
 
-    const int kfid = a.kf_id ? a.kf_id[kp] : 0;
-    const KfDev& kf = a.kfs[kfid];
+    const int kfid = a.kf_id ? G(a.kf_id)[kp] : 0;
+    SVO_GP(const KfDev) kfp = G(a.kfs) + kfid;
+    const KfDev kf = *kfp;            // (scalar loads: the record is wave-uniform)
 
     svo_kp2d ref;
     float nx, ny;
@@ -202,24 +203,24 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         const CamD camd = make_camd(a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy, a.cam);
         svo_kp2d q;
         if (a.proj_mats) {
-            const PoseMats& pm = *a.proj_mats;
-            q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+            const PoseMats pm = *G(a.proj_mats);
+            q = project_point(pm.Rd, pm.t, camd, G(a.kps3d)[kp]);
         } else {
             float pose[6];
-            for (int i = 0; i < 6; i++) pose[i] = a.proj_pose[i];
+            for (int i = 0; i < 6; i++) pose[i] = G(a.proj_pose)[i];
             PoseMats pm;
             pose_mats(pose, pm);
-            q = project_point(pm.Rd, pm.t, camd, a.kps3d[kp]);
+            q = project_point(pm.Rd, pm.t, camd, G(a.kps3d)[kp]);
         }
         nx = q.x; ny = q.y;
-        ref = kf.kps2d[a.kp_index[kp]];
+        ref = G(kf.kps2d)[G(a.kp_index)[kp]];
         if (tid == 0) {
-            a.proj_out[kp] = q;
-            if (a.ref_out) a.ref_out[kp] = ref;
+            G(a.proj_out)[kp] = q;
+            if (a.ref_out) G(a.ref_out)[kp] = ref;
         }
     } else {
-        ref = a.prev_pts[kp];
-        const svo_kp2d q = a.cur_pts[kp];
+        ref = G(a.prev_pts)[kp];
+        const svo_kp2d q = G(a.cur_pts)[kp];
         nx = q.x; ny = q.y;
     }
 
@@ -426,9 +427,9 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     }
 
     if (tid == 0) {
-        a.cur_pts[kp] = svo_kp2d{nx, ny};
-        a.status[kp] = (uint8_t)status;
-        a.err[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
+        G(a.cur_pts)[kp] = svo_kp2d{nx, ny};
+        G(a.status)[kp] = (uint8_t)status;
+        G(a.err)[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
     }
 }
 

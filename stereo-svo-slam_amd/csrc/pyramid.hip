@@ -21,7 +21,7 @@ constexpr int HS_TILE = 64;  // level-0 tile edge; yields levels up to 6 (1x1)
 __device__ inline uint4 load_row16(const ImgView& im, int gy, int gx) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (gy < im.h && gx < im.w) {
-        const uint8_t* p = im.data + (size_t)gy * im.stride + gx;
+        const uint8_t* p = im.g() + (size_t)gy * im.stride + gx;
         if (gx + 16 <= im.w && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
             v = *reinterpret_cast<const uint4*>(p);
         } else {
@@ -35,7 +35,7 @@ __device__ inline uint4 load_row16(const ImgView& im, int gy, int gx) {
 }
 __device__ inline void store_row16(const ImgView& im, int gy, int gx, uint4 v) {
     if (gy >= im.h || gx >= im.w) return;
-    uint8_t* q = const_cast<uint8_t*>(im.data) + (size_t)gy * im.stride + gx;
+    uint8_t* q = im.gw() + (size_t)gy * im.stride + gx;
     if (gx + 16 <= im.w && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
         *reinterpret_cast<uint4*>(q) = v;
     } else {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __re
         }
         const int gy = (y0 >> 1) + r, gx = (x0 >> 1) + c;
         if (gy < d.h) {
-            uint8_t* q = const_cast<uint8_t*>(d.data) + (size_t)gy * d.stride + gx;
+            uint8_t* q = d.gw() + (size_t)gy * d.stride + gx;
             if (gx + 4 <= d.w && ((reinterpret_cast<uintptr_t>(q) & 3) == 0)) {
                 *reinterpret_cast<uint32_t*>(q) = *reinterpret_cast<const uint32_t*>(o);
             } else {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pyr_halfsample_kernel(const PyrArgs* __re
             const uint8_t v = (uint8_t)((p[0] + p[1] + p[edge] + p[edge + 1]) / 4);
             out[r * oe + c] = v;
             const int gy = (y0 >> l) + r, gx = (x0 >> l) + c;
-            if (gy < d.h && gx < d.w) const_cast<uint8_t*>(d.data)[(size_t)gy * d.stride + gx] = v;
+            if (gy < d.h && gx < d.w) d.gw()[(size_t)gy * d.stride + gx] = v;
         }
         __syncthreads();
         uint8_t* tmp = in; in = out; out = tmp;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrArgs* __restrict
     const bool aligned = ((reinterpret_cast<uintptr_t>(src.data) | (uintptr_t)src.stride) & 3) == 0;
     for (int i = tid; i < PD_IH * PD_IWD; i += 256) {
         const int r = i / PD_IWD, d = i - r * PD_IWD;
-        const uint8_t* row = src.data + (size_t)reflect101(iy0 + r, src.h) * src.stride;
+        const uint8_t* row = src.g() + (size_t)reflect101(iy0 + r, src.h) * src.stride;
         const int x = ix0 + 4 * d;
         uint32_t v;
         if (aligned && x >= 0 && x + 4 <= src.w) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrArgs* __restrict
         const uint32_t out4 = o[0] | (o[1] << 16);
         const int gy = oy0 + r, gx = ox0 + 4 * q;
         if (gy < dst.h && gx < dst.w) {
-            uint8_t* p = const_cast<uint8_t*>(dst.data) + (size_t)gy * dst.stride + gx;
+            uint8_t* p = dst.gw() + (size_t)gy * dst.stride + gx;
             if (gx + 4 <= dst.w && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
                 *reinterpret_cast<uint32_t*>(p) = out4;
             } else {

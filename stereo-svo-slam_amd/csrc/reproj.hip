@@ -18,6 +18,8 @@
 // Rotation matrices, the 6x6 solve and the accept logic are wave-uniform and
 // computed redundantly by every lane (no broadcast, no barrier).
 #include "svo_kernels.hpp"
+#include <algorithm>
+#include <atomic>
 
 namespace svo {
 
@@ -29,7 +31,15 @@ struct ReprojShared {
     float sums[28];
 };
 
-typedef float rp_v4f __attribute__((ext_vector_type(4)));
+typedef v4f rp_v4f;
+
+// The keypoints of the sequence, staged once in dynamic LDS (struct of arrays, `cap` entries each):
+// point x y z, observed position x y, and 1 / 0 for "takes part" (none of the ignore flags).
+struct RpKps {
+    SVO_LDS(float)* f;
+    int cap;
+    __device__ inline SVO_LDS(float)* at(int field) const { return f + field * cap; }
+};
 
 template <int WAVES>
 __device__ inline void rp_sync() {
@@ -39,7 +49,7 @@ __device__ inline void rp_sync() {
 
 // cost of PoseRefinerCallback::do_calc
 template <int WAVES>
-__device__ float reproj_cost(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh, int& par) {
+__device__ float reproj_cost(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared& sh, int& par) {
     constexpr int T = 64 * WAVES;
     const int tid = threadIdx.x;
     PoseMats pm;
@@ -52,23 +62,18 @@ __device__ float reproj_cost(const ReprojArgs& a, int n, const float pose[6], Re
         for (int j = tid; j < RP_CHUNK; j += T) {
             const int i = c0 + j;
             float t = 0;
-            if (i < n) {
-                const uint32_t f = a.flags[i];
-                if (!(f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY))) {
-                    const svo_kp2d q = project_point(pm.Rd, pm.t, camd, a.kps3d[i]);
-                    const svo_kp2d k = a.kps2d[i];
-                    const float d0 = fabsf(q.x - k.x), d1 = fabsf(q.y - k.y);
-                    t = d0 + d1;
-                }
+            if (i < n && kp.at(5)[i] != 0.f) {
+                const svo_kp2d q = project_point(pm.Rd, pm.t, camd, svo_kp3d{kp.at(0)[i], kp.at(1)[i], kp.at(2)[i]});
+                const float d0 = fabsf(q.x - kp.at(3)[i]), d1 = fabsf(q.y - kp.at(4)[i]);
+                t = d0 + d1;
             }
-            ((SVO_LDS(float)*)buf)[j] = t;       // skipped keypoints add an exact 0
+            // tot_diff += ... in keypoint order, skipped keypoints add an exact 0 (every lane, same bits)
+            if constexpr (WAVES == 1) tot = ordered_wave_sum(t, tot);
+            else ((SVO_LDS(float)*)buf)[j] = t;
         }
-        rp_sync<WAVES>();
-        const int m = min(RP_CHUNK, n - c0);
-        const SVO_LDS(rp_v4f)* p = (const SVO_LDS(rp_v4f)*)buf;
-        for (int j = 0; j < (m + 3) >> 2; j++) {  // tot_diff += ... in keypoint order (every lane, same bits)
-            const rp_v4f v = p[j];
-            tot += v.x; tot += v.y; tot += v.z; tot += v.w;
+        if constexpr (WAVES > 1) {
+            __syncthreads();
+            tot = ordered_sum(buf, min(RP_CHUNK, n - c0), tot);
         }
     }
     return tot;
@@ -76,7 +81,7 @@ __device__ float reproj_cost(const ReprojArgs& a, int n, const float pose[6], Re
 
 // get_gradient at `pose`: leaves the step in grad[6] (every lane)
 template <int WAVES>
-__device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6], ReprojShared& sh, float grad[6]) {
+__device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared& sh, float grad[6]) {
     constexpr int T = 64 * WAVES;
     const int tid = threadIdx.x;
     PoseMats pm;
@@ -104,19 +109,15 @@ __device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6],
             float J[12], d0 = 0, d1 = 0;
 #pragma unroll
             for (int k = 0; k < 12; k++) J[k] = 0;
-            if (i < n) {
-                const uint32_t f = a.flags[i];
-                if (!(f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY))) {
-                    const svo_kp3d P = a.kps3d[i];
-                    const svo_kp2d q = project_point(pm.Rd, pm.t, camd, P);
-                    float X[3] = {P.x - pm.t[0], P.y - pm.t[1], P.z - pm.t[2]};
-                    mat33f_vec(pm.Ri, X, X);
-                    const svo_kp2d k = a.kps2d[i];
-                    const float e0 = k.x - q.x, e1 = k.y - q.y;
-                    if (!(((double)fabsf(e0) > 3.0) || ((double)fabsf(e1) > 3.0))) {
-                        pose_jacobian(fx, fy, X[0], X[1], X[2], J);
-                        d0 = e0; d1 = e1;
-                    }
+            if (i < n && kp.at(5)[i] != 0.f) {
+                const svo_kp3d P = svo_kp3d{kp.at(0)[i], kp.at(1)[i], kp.at(2)[i]};
+                const svo_kp2d q = project_point(pm.Rd, pm.t, camd, P);
+                float X[3] = {P.x - pm.t[0], P.y - pm.t[1], P.z - pm.t[2]};
+                mat33f_vec(pm.Ri, X, X);
+                const float e0 = kp.at(3)[i] - q.x, e1 = kp.at(4)[i] - q.y;
+                if (!(((double)fabsf(e0) > 3.0) || ((double)fabsf(e1) > 3.0))) {
+                    pose_jacobian(fx, fy, X[0], X[1], X[2], J);
+                    d0 = e0; d1 = e1;
                 }
             }
             // a keypoint that does not take part stages zeros: 0*0 + 0*0 added to a sum changes nothing
@@ -162,44 +163,55 @@ __device__ void reproj_gradient(const ReprojArgs& a, int n, const float pose[6],
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs* __restrict__ args) {
+__global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs* __restrict__ args, int cap) {
     constexpr int T = 64 * WAVES;
     const ReprojArgs& a = args[blockIdx.x];
-    const int n = *a.n_ptr;
+    const int n = min(*G(a.n_ptr), cap);
     const int tid = threadIdx.x;
     __shared__ ReprojShared sh;
+    extern __shared__ __attribute__((aligned(16))) float rp_dyn[];
+    const RpKps kp{(SVO_LDS(float)*)rp_dyn, cap};
 
     if (a.tracked) {   // merge, pose_refinement.cpp:125-150
         for (int i = tid; i < n; i += T) {
-            const svo_kp2d k = a.kps2d[i], t = a.tracked[i];
+            const svo_kp2d k = G(a.kps2d)[i], t = G(a.tracked)[i];
             const float dx = k.x - t.x, dy = k.y - t.y;
             const float diff = dx * dx + dy * dy;
-            uint32_t f = a.flags[i];
-            if (a.err[i] > 20) f |= SVO_IGNORE_COMPLETELY;
+            uint32_t f = G(a.flags)[i];
+            if (G(a.err)[i] > 20) f |= SVO_IGNORE_COMPLETELY;
             else if (diff > 81) f |= SVO_IGNORE_DURING_REFINEMENT;
-            else { f &= ~(uint32_t)SVO_IGNORE_DURING_REFINEMENT; a.kps2d[i] = t; }
-            a.flags[i] = f;
+            else { f &= ~(uint32_t)SVO_IGNORE_DURING_REFINEMENT; G(a.kps2d)[i] = t; }
+            G(a.flags)[i] = f;
         }
         __syncthreads();
     }
+    for (int i = tid; i < n; i += T) {     // the same lane that merged keypoint i
+        const svo_kp3d P = G(a.kps3d)[i];
+        const svo_kp2d k = G(a.kps2d)[i];
+        const uint32_t f = G(a.flags)[i];
+        kp.at(0)[i] = P.x; kp.at(1)[i] = P.y; kp.at(2)[i] = P.z;
+        kp.at(3)[i] = k.x; kp.at(4)[i] = k.y;
+        kp.at(5)[i] = (f & (SVO_IGNORE_DURING_REFINEMENT | SVO_IGNORE_COMPLETELY | SVO_IGNORE_TEMPORARY)) ? 0.f : 1.f;
+    }
+    rp_sync<WAVES>();
 
     float x0[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) x0[j] = a.pose_in[j];
+    for (int j = 0; j < 6; j++) x0[j] = G(a.pose_in)[j];
     const int maxIter = 50;
     int n_grad = 0, n_cost = 1, accepted = 0, exit_small = 0, par = 0;
-    float prev_cost = reproj_cost<WAVES>(a, n, x0, sh, par);
+    float prev_cost = reproj_cost<WAVES>(a, kp, n, x0, sh, par);
     const float initial = prev_cost;
     for (int i = 0; i < maxIter; i++) {
         float g[6];
-        reproj_gradient<WAVES>(a, n, x0, sh, g);
+        reproj_gradient<WAVES>(a, kp, n, x0, sh, g);
         n_grad++;
         float k = 1.0f;
         for (; i < maxIter; i++) {
             float x[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) x[j] = x0[j] + k * g[j];
-            const float new_cost = reproj_cost<WAVES>(a, n, x, sh, par);
+            const float new_cost = reproj_cost<WAVES>(a, kp, n, x, sh, par);
             n_cost++;
             if (new_cost < prev_cost) {
 #pragma unroll
@@ -216,23 +228,54 @@ __global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs*
         }
     }
     if (tid == 0) {
-        for (int j = 0; j < 6; j++) a.pose_out[j] = x0[j];
-        if (a.cost_out) *a.cost_out = prev_cost;
+        for (int j = 0; j < 6; j++) G(a.pose_out)[j] = x0[j];
+        if (a.cost_out) *G(a.cost_out) = prev_cost;
         if (a.trace) {
             svo_gn_trace t;
             t.level = 0; t.n_gradient = n_grad; t.n_cost = n_cost; t.n_accepted = accepted;
             t.exit_small = exit_small; t.initial_cost = initial; t.final_cost = prev_cost;
             for (int j = 0; j < 6; j++) t.pose[j] = x0[j];
-            *a.trace = t;
+            *G(a.trace) = t;
         }
     }
 }
 
-void launch_reproj(const ReprojArgs* d_args, int batch, hipStream_t stream) {
-    if (batch >= 16)
-        hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), 0, stream, d_args);
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ pose, const svo_kp3d* __restrict__ kps3d,
+                                                      int n, svo_camera_settings cam, svo_kp2d* __restrict__ out) {
+    float p[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) p[j] = pose[j];
+    PoseMats pm;
+    pose_mats(p, pm);
+    const CamD camd = make_camd(cam.fx, cam.fy, cam.cx, cam.cy, cam);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = project_point(pm.Rd, pm.t, camd, kps3d[i]);
+}
+
+void launch_project(const float* pose, const svo_kp3d* kps3d, int n, const svo_camera_settings& cam,
+                    svo_kp2d* out, hipStream_t stream) {
+    hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pose, kps3d, n, cam, out);
+}
+
+// n_bound: upper bound of the keypoint counts of the launch (sizes the LDS copy of the keypoints:
+// 24 B each). One wave per sequence up to 128 keypoints, four beyond. Returns false when the
+// keypoints do not fit LDS (more than ~5000).
+bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t stream) {
+    const int cap = (std::max(n_bound, 1) + 255) & ~255;
+    const size_t lds = (size_t)cap * 6 * sizeof(float);
+    if (lds > 120 * 1024) return false;
+    static std::atomic<bool> configured{false};
+    if (!configured.exchange(true)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    }
+    if (n_bound <= 128)
+        hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), lds, stream, d_args, cap);
     else
-        hipLaunchKernelGGL(reproj_gn_kernel<4>, dim3(batch), dim3(256), 0, stream, d_args);
+        hipLaunchKernelGGL(reproj_gn_kernel<4>, dim3(batch), dim3(256), lds, stream, d_args, cap);
+    return true;
 }
 
 }  // namespace svo

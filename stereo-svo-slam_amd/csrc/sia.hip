@@ -43,20 +43,24 @@ namespace svo {
 
 constexpr size_t SIA_LDS_BUDGET = 156 * 1024;
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 #define LDSF(p) ((SVO_LDS(float)*)(p))
 #define LDSCF(p) ((const SVO_LDS(float)*)(p))
 
-// the current level image in LDS (rows padded to a dword)
+// the current level image: the LDS copy (rows padded to a dword) or, for level images too large
+// for LDS (BIG), the image in HBM / L2
+template <bool BIG>
 struct LevelImg {
-    const uint8_t* p;       // LDS
+    const uint8_t* p;
     int w, h, stride;
-    __device__ inline float at(int o) const { return (float)((const SVO_LDS(uint8_t)*)p)[o]; }
+    __device__ inline float at(int o) const {
+        if constexpr (BIG) return (float)((SVO_GP(const uint8_t))p)[o];
+        else return (float)((const SVO_LDS(uint8_t)*)p)[o];
+    }
 };
 
-// get_patch_sum, src/lib/pose_estimator.cpp:82-112, on the LDS image
-__device__ inline float patch_sum_lds(const LevelImg& im, float cx, float cy) {
+// get_patch_sum, src/lib/pose_estimator.cpp:82-112, on the level image
+template <bool BIG>
+__device__ inline float patch_sum_lds(const LevelImg<BIG>& im, float cx, float cy) {
     const float sx = cx - 0.5f, sy = cy - 0.5f;
     const int ipx = (int)floorf(sx), ipy = (int)floorf(sy);
     const float x2 = sx - (float)ipx, y2 = sy - (float)ipy;
@@ -72,16 +76,6 @@ __device__ inline float patch_sum_lds(const LevelImg& im, float cx, float cy) {
     return intensity;
 }
 
-// sequential sum of buf[0..n) (LDS, zero padded to a multiple of 4) continuing from s
-__device__ inline float ordered_sum(const float* buf, int n, float s) {
-    const SVO_LDS(v4f)* p = (const SVO_LDS(v4f)*)buf;
-    for (int j = 0; j < (n + 3) >> 2; j++) {
-        const v4f v = p[j];
-        s += v.x; s += v.y; s += v.z; s += v.w;
-    }
-    return s;
-}
-
 // Dynamic LDS of one workgroup (byte offsets). cap = keypoint capacity (multiple of 64),
 // T = threads. Per keypoint: 9 floats (point, last projection, sum g g^T, active) and the
 // 64 per-pixel records, all struct-of-arrays with the keypoint index fastest (conflict free).
@@ -90,15 +84,15 @@ enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
 struct SiaLds {
     size_t img, tbuf, kpf, rec, sums, stage, total;
 };
-__host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact) {
+__host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact, bool big = false) {
     SiaLds l;
     size_t off = 0;
-    l.img = off;   off += ((size_t)img_bytes + 15) & ~(size_t)15;
+    l.img = off;   off += big ? 0 : ((size_t)img_bytes + 15) & ~(size_t)15;
     l.tbuf = off;  off += (size_t)2 * cap * 4;
-    l.kpf = off;   off += (size_t)KF_COUNT * cap * 4;
-    l.rec = off;   off += (size_t)64 * cap * 4;
+    l.kpf = off;   off += big ? 0 : (size_t)KF_COUNT * cap * 4;
+    l.rec = off;   off += big ? 0 : (size_t)64 * cap * 4;
     l.sums = off;  off += 16 * 32 * 4;                                 // [WAVES <= 16][32]
-    l.stage = off; off += exact ? (size_t)7 * (64 * 16 + 4) * 4 : 0;  // 7 planes of one wave's rows, padded: distinct banks per plane
+    l.stage = off; off += exact ? (size_t)7 * (64 * 20 + 4) * 4 : 0;  // 7 planes of one wave's rows (20 floats per keypoint)
     l.total = off;
     return l;
 }
@@ -124,7 +118,7 @@ constexpr int SIA_REC_ROWS = 68;
 
 __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict__ args) {
     const SiaArgs& a = args[blockIdx.z];
-    const int n = min(*a.n_ptr, a.rec_cap);
+    const int n = min(*G(a.n_ptr), a.rec_cap);
     const int level = a.cam.min_pyramid_level_pose_estimation + blockIdx.y;
     if (level >= a.cam.max_pyramid_levels) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -134,9 +128,9 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
     const ImgView prev = a.prev[level];
     const int divider = 1 << level;
     float g0 = 0, g1 = 0, psr = __builtin_nanf(""), i1 = __builtin_nanf("");
-    const bool active = kp < n && !(a.flags && (a.flags[kp] & SVO_IGNORE_TEMPORARY));
+    const bool active = kp < n && !(a.flags && (G(a.flags)[kp] & SVO_IGNORE_TEMPORARY));
     if (active) {
-        svo_kp2d kref = a.kps2d[kp];
+        svo_kp2d kref = G(a.kps2d)[kp];
         if (level != 0) { kref.x /= divider; kref.y /= divider; }      // setLevel
         // the reference's walk over the patch: x++ per column, x -= 4 and y++ per row (float arithmetic)
         float kx = kref.x - 2.f, ky = kref.y - 2.f;
@@ -149,16 +143,16 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
         // calculate_hessian bounds (:351-352)
         if (!(((double)kx - 2.0) < 0 || ((double)ky - 2.0) < 0 ||
               ((double)kx + 3.0) >= prev.w || ((double)ky + 3.0) >= prev.h)) {
-            const float int1 = patch_sum(prev.data, prev.stride, kx + 1, ky);
-            const float int2 = patch_sum(prev.data, prev.stride, kx - 1, ky);
-            const float int3 = patch_sum(prev.data, prev.stride, kx, ky + 1);
-            const float int4 = patch_sum(prev.data, prev.stride, kx, ky - 1);
+            const float int1 = patch_sum(prev.g(), prev.stride, kx + 1, ky);
+            const float int2 = patch_sum(prev.g(), prev.stride, kx - 1, ky);
+            const float int3 = patch_sum(prev.g(), prev.stride, kx, ky + 1);
+            const float int4 = patch_sum(prev.g(), prev.stride, kx, ky - 1);
             g0 = int1 - int2; g1 = int3 - int4;
         }
         // reference half of the residual test (:449-453)
         if (!(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
               ((double)kx + 2.0) > prev.w || ((double)ky + 2.0) > prev.h))
-            psr = patch_sum(prev.data, prev.stride, kx, ky);
+            psr = patch_sum(prev.g(), prev.stride, kx, ky);
         // reference half of the cost (image_comparison.cpp:20-88): one window test per keypoint
         const int ps = a.cam.window_size_pose_estimator;
         const float half_size = ((float)ps - 1.0f) / 2.0f;
@@ -170,7 +164,7 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
                 const float x12 = s1x - (float)ip1x, y12 = s1y - (float)ip1y;
                 const float x11 = 1.0f - x12, y11 = 1.0f - y12;
                 const float m0 = x11 * y11, m1 = x12 * y11, m2 = x11 * y12, m3 = x12 * y12;
-                const uint8_t* p = prev.data + (size_t)((px >> 2) + ip1y) * prev.stride + (px & 3) + ip1x;
+                const uint8_t* p = prev.g() + (size_t)((px >> 2) + ip1y) * prev.stride + (px & 3) + ip1x;
                 float t = 0;
                 t += m0 * (float)p[0];
                 t += m1 * (float)p[1];
@@ -180,7 +174,7 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
             }
         }
     }
-    float* out = a.rec_ws + (size_t)blockIdx.y * SIA_REC_ROWS * a.rec_cap;
+    float* out = G(a.rec_ws) + (size_t)blockIdx.y * SIA_REC_ROWS * a.rec_cap;
     out[(size_t)(REC_I1 * 16 + px) * a.rec_cap + kp] = i1;
     out[(size_t)(REC_PS * 16 + px) * a.rec_cap + kp] = psr;
     out[(size_t)(REC_G0 * 16 + px) * a.rec_cap + kp] = g0;
@@ -202,7 +196,11 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
 #define SIA_ADD(i, t1, t0)
 #endif
 
-template <int WAVES>
+// BIG: keypoint sets / level images that do not fit LDS (the 1920x1080 configuration: ~1700
+// keypoints, 480x270 finest level). The per-keypoint values then live in the HBM workspace
+// SiaArgs::kp_ws, the records are read where sia_prep_kernel wrote them and the image taps come
+// from L2; the arithmetic and its order are the same.
+template <int WAVES, bool BIG>
 struct Sia {
     static constexpr int T = 64 * WAVES;
 #ifdef SVO_SIA_STAMPS
@@ -213,7 +211,8 @@ struct Sia {
     int n, cap;
     uint8_t* dyn;
     SiaLds lay;
-    LevelImg cur;
+    LevelImg<BIG> cur;
+    const float* recs = nullptr;     // BIG: records of the level in HBM, rows of a.rec_cap
     float fx, fy, cx, cy;
     int patch;
     int par = 0;
@@ -221,19 +220,45 @@ struct Sia {
     __device__ Sia(const SiaArgs& a_, int n_, int cap_, uint8_t* dyn_, const SiaLds& lay_)
         : a(a_), n(n_), cap(cap_), dyn(dyn_), lay(lay_) {}
 
-    __device__ inline SVO_LDS(float)* kpf(int f) const { return LDSF(dyn + lay.kpf) + f * cap; }
-    __device__ inline SVO_LDS(float)* rec(int f, int px) const { return LDSF(dyn + lay.rec) + (f * 16 + px) * cap; }
+    __device__ inline float kpf_ld(int f, int i) const {
+        if constexpr (BIG) return G(a.kp_ws)[(size_t)f * cap + i];
+        else return (LDSF(dyn + lay.kpf) + f * cap)[i];
+    }
+    __device__ inline void kpf_st(int f, int i, float v) const {
+        if constexpr (BIG) G(a.kp_ws)[(size_t)f * cap + i] = v;
+        else (LDSF(dyn + lay.kpf) + f * cap)[i] = v;
+    }
+    __device__ inline float rec_ld(int f, int px, int i) const {
+        if constexpr (BIG) return ((SVO_GP(const float))recs)[(size_t)(f * 16 + px) * a.rec_cap + i];
+        else return (LDSF(dyn + lay.rec) + (f * 16 + px) * cap)[i];
+    }
+    __device__ inline float g_ld(int k, int i) const {       // sum g g^T: Gxx, Gxy, Gyy
+        if constexpr (BIG) return ((SVO_GP(const float))recs)[(size_t)(64 + k) * a.rec_cap + i];
+        else return (LDSF(dyn + lay.kpf) + (KF_GXX + k) * cap)[i];
+    }
 
     // ---- per-level records (sia_prep_kernel wrote them): HBM -> LDS, 16 B per lane and step
     __device__ void load_records(int slot) {
-        const float* src = a.rec_ws + (size_t)slot * SIA_REC_ROWS * a.rec_cap;
+        const float* src = G(a.rec_ws) + (size_t)slot * SIA_REC_ROWS * a.rec_cap;
+        if constexpr (BIG) { recs = src; return; }
+        // cap is a multiple of T, so a lane keeps its float4 column and walks the 67 rows, 8 loads in flight
         const int c4 = cap >> 2;
-        for (int e = threadIdx.x; e < 67 * c4; e += T) {
-            const int row = e / c4, col = (e - row * c4) * 4;
-            const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)row * a.rec_cap + col);
-            SVO_LDS(float)* dst = row < 64 ? LDSF(dyn + lay.rec) + row * cap + col
-                                           : kpf(KF_GXX + (row - 64)) + col;
-            *(SVO_LDS(v4f)*)dst = v;
+        for (int col4 = threadIdx.x; col4 < c4; col4 += T) {
+            for (int r0 = 0; r0 < 67; r0 += 8) {
+                v4f v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (r0 + u < 67) v[u] = *reinterpret_cast<const v4f*>(src + (size_t)(r0 + u) * a.rec_cap + 4 * col4);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int row = r0 + u;
+                    if (row < 67) {
+                        SVO_LDS(float)* dst = row < 64 ? LDSF(dyn + lay.rec) + row * cap + 4 * col4
+                                                       : LDSF(dyn + lay.kpf) + (KF_GXX + (row - 64)) * cap + 4 * col4;
+                        *(SVO_LDS(v4f)*)dst = v[u];
+                    }
+                }
+            }
         }
     }
 
@@ -248,14 +273,15 @@ struct Sia {
         const float half_size = ((float)ps - 1.0f) / 2.0f;
         float* buf = reinterpret_cast<float*>(dyn + lay.tbuf) + par * cap;
         par ^= 1;
+        float total = 0;
         for (int i = threadIdx.x; i < cap; i += T) {
             float v = 0;
-            if (kpf(KF_ACT)[i] != 0.f) {
-                const svo_kp2d q = project_point(pm.Rd, pm.t, camd, svo_kp3d{kpf(KF_PX)[i], kpf(KF_PY)[i], kpf(KF_PZ)[i]});
-                kpf(KF_QX)[i] = q.x; kpf(KF_QY)[i] = q.y;
+            if (kpf_ld(KF_ACT, i) != 0.f) {
+                const svo_kp2d q = project_point(pm.Rd, pm.t, camd, svo_kp3d{kpf_ld(KF_PX, i), kpf_ld(KF_PY, i), kpf_ld(KF_PZ, i)});
+                kpf_st(KF_QX, i, q.x); kpf_st(KF_QY, i, q.y);
                 const float s2x = q.x - half_size, s2y = q.y - half_size;
                 const float f2x = floorf(s2x), f2y = floorf(s2y);
-                const float i1_0 = rec(REC_I1, 0)[i];
+                const float i1_0 = rec_ld(REC_I1, 0, i);
                 // (absurd projections are kept out of the int conversion)
                 if (i1_0 == i1_0 && f2x >= 0.f && f2y >= 0.f && f2x < 65536.f && f2y < 65536.f) {
                     const int ip2x = (int)f2x, ip2y = (int)f2y;
@@ -277,16 +303,20 @@ struct Sia {
                             i2 += m1 * b[r][c + 1];
                             i2 += m2 * b[r + 1][c];
                             i2 += m3 * b[r + 1][c + 1];
-                            v += fabsf(rec(REC_I1, px)[i] - i2);
+                            v += fabsf(rec_ld(REC_I1, px, i) - i2);
                         }
                     }
                 }
             }
-            LDSF(buf)[i] = v;                          // inactive / outside: an exact 0
+            // diff += ... in keypoint order (inactive / outside: an exact 0): same bits in every lane
+            if constexpr (WAVES == 1) total = ordered_wave_sum(v, total);
+            else LDSF(buf)[i] = v;
         }
-        sia_sync<WAVES>();
         SIA_T(c2);
-        const float total = ordered_sum(buf, n, 0.f);  // diff += ... in keypoint order: same bits in every lane
+        if constexpr (WAVES > 1) {
+            __syncthreads();
+            total = ordered_sum(buf, n, 0.f);
+        }
         SIA_T(c3);
         SIA_ADD(1, c1, c0); SIA_ADD(2, c2, c1); SIA_ADD(3, c3, c2); SIA_ADD(4, 1, 0);
         return total;
@@ -309,7 +339,9 @@ struct Sia {
         if (lane < 21) { ia = c_tri_r[lane]; ib = c_tri_c[lane]; }
         else if (lane < 27) { ia = lane - 21; ib = 6; }
         float eacc = 0;
-        constexpr int PS = 64 * 16 + 4;
+        const float wlim = (float)(cur.w - 2), hlim = (float)(cur.h - 2);
+        constexpr int KS = 20;                       // floats per keypoint in a staging plane (16 + pad: no write conflicts)
+        constexpr int PS = 64 * KS + 4;              // plane stride: the 7 planes start on different banks
         float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index px*64 + lane
 
         for (int i0 = 0; i0 < cap; i0 += T) {
@@ -317,16 +349,16 @@ struct Sia {
             float J[12];
 #pragma unroll
             for (int q = 0; q < 12; q++) J[q] = 0;
-            const bool active = kpf(KF_ACT)[i] != 0.f;
+            const bool active = kpf_ld(KF_ACT, i) != 0.f;
             if (active) {
-                float X[3] = {kpf(KF_PX)[i] - pm.t[0], kpf(KF_PY)[i] - pm.t[1], kpf(KF_PZ)[i] - pm.t[2]};
+                float X[3] = {kpf_ld(KF_PX, i) - pm.t[0], kpf_ld(KF_PY, i) - pm.t[1], kpf_ld(KF_PZ, i) - pm.t[2]};
                 mat33f_vec(pm.Ri, X, X);
                 pose_jacobian(fx, fy, X[0], X[1], X[2], J);
             }
             // residuals: the same walk over the patch as above, from the projection
             float d[16];
             {
-                float kx = kpf(KF_QX)[i] - 2.f, ky = kpf(KF_QY)[i] - 2.f;
+                float kx = kpf_ld(KF_QX, i) - 2.f, ky = kpf_ld(KF_QY, i) - 2.f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -334,10 +366,11 @@ struct Sia {
                         const int px = r * 4 + c;
                         float dd = 0;
                         if (active) {
-                            const float psr = rec(REC_PS, px)[i];
+                            const float psr = rec_ld(REC_PS, px, i);
+                            // (kx - 1.0) < 0 || (ky - 1.0) < 0 || (kx + 2.0) > cols || (ky + 2.0) > rows of :449-454:
+                            // the double sums are exact, so these float compares decide the same way
                             if (psr == psr &&                   // reference pixel inside (:449-451)
-                                !(((double)kx - 1.0) < 0 || ((double)ky - 1.0) < 0 ||
-                                  ((double)kx + 2.0) > cur.w || ((double)ky + 2.0) > cur.h))
+                                !(kx < 1.f || ky < 1.f || kx > wlim || ky > hlim))
                                 dd = patch_sum_lds(cur, kx, ky) - psr;
                         }
                         d[px] = dd;
@@ -352,10 +385,10 @@ struct Sia {
                 if (active) {                               // (slots past the keypoints hold no records)
 #pragma unroll
                     for (int px = 0; px < 16; px++) {
-                        s0 += rec(REC_G0, px)[i] * d[px];
-                        s1 += rec(REC_G1, px)[i] * d[px];
+                        s0 += rec_ld(REC_G0, px, i) * d[px];
+                        s1 += rec_ld(REC_G1, px, i) * d[px];
                     }
-                    Gxx = kpf(KF_GXX)[i]; Gxy = kpf(KF_GXY)[i]; Gyy = kpf(KF_GYY)[i];
+                    Gxx = g_ld(0, i); Gxy = g_ld(1, i); Gyy = g_ld(2, i);
                 }
                 int q = 0;
 #pragma unroll
@@ -374,16 +407,28 @@ struct Sia {
                     sia_sync<WAVES>();                      // the previous 64 keypoints have been consumed
                     if (wave == w) {
 #pragma unroll
-                        for (int px = 0; px < 16; px++) {
-                            const float g0 = active ? rec(REC_G0, px)[i] : 0.f, g1 = active ? rec(REC_G1, px)[i] : 0.f;
+                        for (int p4 = 0; p4 < 4; p4++) {
+                            float g0[4], g1[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                g0[e] = active ? rec_ld(REC_G0, p4 * 4 + e, i) : 0.f;
+                                g1[e] = active ? rec_ld(REC_G1, p4 * 4 + e, i) : 0.f;
+                            }
 #pragma unroll
                             for (int q = 0; q < 6; q++) {
-                                float sum = 0;
-                                sum += g0 * J[q];
-                                sum += g1 * J[6 + q];
-                                LDSF(stage)[q * PS + px * 64 + lane] = sum;
+                                v4f row;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    float sum = 0;
+                                    sum += g0[e] * J[q];
+                                    sum += g1[e] * J[6 + q];
+                                    row[e] = sum;
+                                }
+                                *(SVO_LDS(v4f)*)(LDSF(stage) + q * PS + lane * KS + p4 * 4) = row;
                             }
-                            LDSF(stage)[6 * PS + px * 64 + lane] = d[px];
+                            // residual -= row * diff (:472-477) == residual += row * (-diff), exactly
+                            *(SVO_LDS(v4f)*)(LDSF(stage) + 6 * PS + lane * KS + p4 * 4) =
+                                v4f{-d[p4 * 4], -d[p4 * 4 + 1], -d[p4 * 4 + 2], -d[p4 * 4 + 3]};
                         }
                     }
                     sia_sync<WAVES>();
@@ -391,14 +436,17 @@ struct Sia {
                         const int m = min(64, n - (i0 + w * 64));   // keypoints of this chunk, in index order
                         const SVO_LDS(float)* pa = LDSCF(stage) + ia * PS;
                         const SVO_LDS(float)* pb = LDSCF(stage) + ib * PS;
-                        if (lane < 21) {
-                            for (int j = 0; j < m; j++)
-#pragma unroll
-                                for (int px = 0; px < 16; px++) eacc += pa[px * 64 + j] * pb[px * 64 + j];
-                        } else {
-                            for (int j = 0; j < m; j++)
-#pragma unroll
-                                for (int px = 0; px < 16; px++) eacc -= pa[px * 64 + j] * pb[px * 64 + j];
+                        // hessian += row^T row (lanes 0..20), residual += row * (-diff) (lanes 21..26):
+                        // one multiply and one add of the chain per patch pixel, in storage order
+                        for (int j = 0; j < m; j++) {
+                            const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + j * KS);
+                            const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + j * KS);
+                            const v4f a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+                            const v4f b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
+                            eacc += a0.x * b0.x; eacc += a0.y * b0.y; eacc += a0.z * b0.z; eacc += a0.w * b0.w;
+                            eacc += a1.x * b1.x; eacc += a1.y * b1.y; eacc += a1.z * b1.z; eacc += a1.w * b1.w;
+                            eacc += a2.x * b2.x; eacc += a2.y * b2.y; eacc += a2.z * b2.z; eacc += a2.w * b2.w;
+                            eacc += a3.x * b3.x; eacc += a3.y * b3.y; eacc += a3.z * b3.z; eacc += a3.w * b3.w;
                         }
                     }
                 }
@@ -462,28 +510,40 @@ struct Sia {
 
     // stage one level image into LDS (rows padded to a dword)
     __device__ void stage_image(const ImgView im) {
+        if constexpr (BIG) { cur = LevelImg<BIG>{im.data, im.w, im.h, im.stride}; return; }
         const int tid = threadIdx.x;
         uint8_t* sc = dyn + lay.img;
         const int ls = (im.w + 3) & ~3;
         if ((((uintptr_t)im.data | (uintptr_t)im.stride) & 3) == 0) {
             const int wd = im.w >> 2;                       // whole dwords per row
-            for (int i = tid; i < wd * im.h; i += T) {
-                const int r = i / wd, c = i - r * wd;
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(im.data + (size_t)r * im.stride + 4 * c);
-                *(SVO_LDS(uint32_t)*)(sc + r * ls + 4 * c) = v;
+            // 64 lanes share a row segment (coalesced); a wave takes every WAVES-th group of 8 rows:
+            // 8 loads in flight per lane, no divisions
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int c0 = 0; c0 < wd; c0 += 64) {
+                const int c = c0 + lane;
+                for (int r0 = wave * 8; r0 < im.h; r0 += 8 * WAVES) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (c < wd && r0 + u < im.h)
+                            v[u] = *reinterpret_cast<const uint32_t*>(im.g() + (size_t)(r0 + u) * im.stride + 4 * c);
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (c < wd && r0 + u < im.h) *(SVO_LDS(uint32_t)*)(sc + (r0 + u) * ls + 4 * c) = v[u];
+                }
             }
             const int tail = im.w & 3;
             for (int i = tid; i < tail * im.h; i += T) {
                 const int r = i / tail, c = wd * 4 + (i - r * tail);
-                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.data[(size_t)r * im.stride + c];
+                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.g()[(size_t)r * im.stride + c];
             }
         } else {
             for (int i = tid; i < im.w * im.h; i += T) {
                 const int r = i / im.w, c = i - r * im.w;
-                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.data[(size_t)r * im.stride + c];
+                *(SVO_LDS(uint8_t)*)(sc + r * ls + c) = im.g()[(size_t)r * im.stride + c];
             }
         }
-        cur = LevelImg{sc, im.w, im.h, ls};
+        cur = LevelImg<BIG>{sc, im.w, im.h, ls};
     }
 
     __device__ void run() {
@@ -491,17 +551,17 @@ struct Sia {
         patch = a.cam.window_size_pose_estimator;
         // active set and points (PoseEstimatorCallback ctor, :238-245)
         for (int i = tid; i < cap; i += T) {
-            const bool active = i < n && !(a.flags && (a.flags[i] & SVO_IGNORE_TEMPORARY));
+            const bool active = i < n && !(a.flags && (G(a.flags)[i] & SVO_IGNORE_TEMPORARY));
             svo_kp3d P = {0, 0, 0};
-            if (active) P = a.kps3d[i];
-            kpf(KF_PX)[i] = P.x; kpf(KF_PY)[i] = P.y; kpf(KF_PZ)[i] = P.z;
-            kpf(KF_QX)[i] = 0; kpf(KF_QY)[i] = 0;
-            kpf(KF_ACT)[i] = active ? 1.f : 0.f;
+            if (active) P = G(a.kps3d)[i];
+            kpf_st(KF_PX, i, P.x); kpf_st(KF_PY, i, P.y); kpf_st(KF_PZ, i, P.z);
+            kpf_st(KF_QX, i, 0.f); kpf_st(KF_QY, i, 0.f);
+            kpf_st(KF_ACT, i, active ? 1.f : 0.f);
         }
         SIA_T(k0);
         float est[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) est[j] = a.pose_guess[j];
+        for (int j = 0; j < 6; j++) est[j] = G(a.pose_guess)[j];
         float last_cost = 0;
         bool dbg_done = false;
 
@@ -529,7 +589,7 @@ struct Sia {
             float prev_cost = cost(x0);
             const float initial = prev_cost;
             for (int i = 0; i < maxIter; i++) {
-                float* dbg = (a.dbg_H && !dbg_done && level == a.dbg_level) ? a.dbg_H : nullptr;
+                float* dbg = (a.dbg_H && !dbg_done && level == a.dbg_level) ? (float*)G(a.dbg_H) : nullptr;
                 float g[6];
                 gradient(x0, g, dbg);
                 if (dbg) dbg_done = true;
@@ -563,34 +623,34 @@ struct Sia {
                 t.level = level; t.n_gradient = n_grad; t.n_cost = n_cost; t.n_accepted = accepted;
                 t.exit_small = exit_small; t.initial_cost = initial; t.final_cost = prev_cost;
                 for (int j = 0; j < 6; j++) t.pose[j] = x0[j];
-                a.trace[level] = t;
+                G(a.trace)[level] = t;
             }
         }
 #ifdef SVO_SIA_STAMPS
         if (tid == 0 && a.dbg_H) {
             st[9] = __builtin_readcyclecounter() - k0;
-            for (int j = 0; j < 12; j++) a.dbg_H[j] = (float)st[j];
+            for (int j = 0; j < 12; j++) G(a.dbg_H)[j] = (float)st[j];
         }
 #endif
         if (tid == 0) {
-            for (int j = 0; j < 6; j++) a.pose_out[j] = est[j];
-            if (a.cost_out) *a.cost_out = last_cost;
+            for (int j = 0; j < 6; j++) G(a.pose_out)[j] = est[j];
+            if (a.cost_out) *G(a.cost_out) = last_cost;
             if (a.mats_out) {    // once per sequence instead of once per keypoint workgroup of klt_track_kernel
                 PoseMats pm;
                 pose_mats(est, pm);
-                *a.mats_out = pm;
+                *G(a.mats_out) = pm;
             }
         }
     }
 };
 
-template <int WAVES>
+template <int WAVES, bool BIG>
 __global__ __launch_bounds__(64 * WAVES) void sia_gn_kernel(const SiaArgs* __restrict__ args, int img_bytes, int cap) {
     const SiaArgs& a = args[blockIdx.x];
-    const int n = min(*a.n_ptr, cap);
+    const int n = min(*G(a.n_ptr), cap);
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    const SiaLds lay = sia_lds_layout(img_bytes, cap, 64 * WAVES, a.exact_pinv != 0);
-    Sia<WAVES> s(a, n, cap, dyn, lay);
+    const SiaLds lay = sia_lds_layout(img_bytes, cap, 64 * WAVES, a.exact_pinv != 0, BIG);
+    Sia<WAVES, BIG> s(a, n, cap, dyn, lay);
     s.run();
 }
 
@@ -605,43 +665,48 @@ static int sia_img_bytes(const svo_camera_settings& cam, int width, int height) 
     return best;
 }
 
-template <int WAVES>
+template <int WAVES, bool BIG>
 static void sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap, size_t lds, hipStream_t stream) {
     static std::atomic<bool> configured{false};
     if (!configured.exchange(true))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES, BIG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIA_LDS_BUDGET);
-    hipLaunchKernelGGL((sia_gn_kernel<WAVES>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
+    hipLaunchKernelGGL((sia_gn_kernel<WAVES, BIG>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
 }
 
-void launch_sia_big(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
-                    int height, int n_bound, hipStream_t stream);   // sia_big.hip
-
-// Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints. Many sequences:
-// few waves (several sequences per CU, little redundant uniform work); a lone sequence: one
-// keypoint per lane as long as the waves last.
-void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+// Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints, one keypoint per
+// lane and pass. Sets that fit LDS (records 256 B per keypoint + the finest level image): as many
+// waves as 64-keypoint passes (up to 8) for a few sequences, half as many for a batch. Larger ones (BIG): 8 waves, several passes, records and
+// per-keypoint values in the HBM workspaces. Returns false if n_bound exceeds the workspaces.
+bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int n_bound, int rec_cap, int exact, hipStream_t stream) {
     const int nb = std::max(n_bound, 1);
-    int waves;
-    if (batch >= 16) waves = nb <= 128 ? 1 : nb <= 256 ? 2 : 4;
-    else waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
-    const int T = 64 * waves;
-    const int cap = (nb + T - 1) / T * T;             // every lane of every pass owns a slot
-    const int img = sia_img_bytes(cam, width, height);
-    const size_t lds = sia_lds_layout(img, cap, 64 * waves, exact != 0).total;
-    if (lds > SIA_LDS_BUDGET || cap > rec_cap) {
-        launch_sia_big(d_args, batch, cam, width, height, n_bound, stream);
-        return;
-    }
     const int n_lv = cam.max_pyramid_levels - cam.min_pyramid_level_pose_estimation;
-    hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 255) / 256, n_lv, batch), dim3(256), 0, stream, d_args);
-    switch (waves) {
-        case 1: sia_launch_shape<1>(d_args, batch, img, cap, lds, stream); break;
-        case 2: sia_launch_shape<2>(d_args, batch, img, cap, lds, stream); break;
-        case 4: sia_launch_shape<4>(d_args, batch, img, cap, lds, stream); break;
-        default: sia_launch_shape<8>(d_args, batch, img, cap, lds, stream); break;
+    const int img = sia_img_bytes(cam, width, height);
+    // many sequences: half as many waves (two passes each) — the wave-uniform work (SVD, Rodrigues,
+    // the ordered sums) is then not duplicated on a second SIMD that other kernels could use
+    int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
+    if (batch >= 32 && waves > 1 && waves < 8) waves /= 2;
+    int T = 64 * waves;
+    int cap = (nb + T - 1) / T * T;                   // every lane of every pass owns a slot
+    size_t lds = sia_lds_layout(img, cap, T, exact != 0).total;
+    const bool big = lds > SIA_LDS_BUDGET;
+    if (big) {
+        waves = 8; T = 512;
+        cap = (nb + T - 1) / T * T;
+        lds = sia_lds_layout(img, cap, T, exact != 0, true).total;
+        if (lds > SIA_LDS_BUDGET) return false;
     }
+    if (cap > rec_cap) return false;
+    hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 255) / 256, n_lv, batch), dim3(256), 0, stream, d_args);
+    if (big) { sia_launch_shape<8, true>(d_args, batch, img, cap, lds, stream); return true; }
+    switch (waves) {
+        case 1: sia_launch_shape<1, false>(d_args, batch, img, cap, lds, stream); break;
+        case 2: sia_launch_shape<2, false>(d_args, batch, img, cap, lds, stream); break;
+        case 4: sia_launch_shape<4, false>(d_args, batch, img, cap, lds, stream); break;
+        default: sia_launch_shape<8, false>(d_args, batch, img, cap, lds, stream); break;
+    }
+    return true;
 }
 
 size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap) {

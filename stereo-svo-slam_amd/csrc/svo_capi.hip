@@ -48,8 +48,7 @@ struct svo_handle {
     int max_kps;
     uint8_t* ring;       // device ring for argument blocks
     size_t ring_cap, ring_off;
-    float4* sia_cache;   // [max_kps*16]
-    float* sia_kpws;     // [max_kps*8]
+    float* sia_kpws;     // [9][rec_cap] per-keypoint values of the BIG alignment path
     float* sia_rec;      // [7][68][rec_cap] per-level alignment records
     int rec_cap;
     KfDev* kf_one;       // 1-entry keyframe table for svo_klt_track
@@ -71,15 +70,14 @@ extern "C" int svo_handle_create(int device, int max_keypoints, svo_handle** out
     h->device = device;
     h->stream = nullptr;
     h->max_kps = max_keypoints;
-    h->exact_pinv = 0;
+    h->exact_pinv = 1;     // reference-order Gauss-Newton by default
     h->ring_cap = 1 << 20;
     h->ring_off = 0;
     HIP_TRY(hipMalloc(&h->ring, h->ring_cap));
-    HIP_TRY(hipMalloc(&h->sia_cache, sizeof(float4) * 16 * (size_t)max_keypoints));
-    HIP_TRY(hipMalloc(&h->sia_kpws, sizeof(float) * 40 * (size_t)(max_keypoints + 16)));
     HIP_TRY(hipMalloc(&h->kf_one, sizeof(KfDev)));
     h->rec_cap = (max_keypoints + 511) / 512 * 512;
     HIP_TRY(hipMalloc(&h->sia_rec, sizeof(float) * 7 * 68 * (size_t)h->rec_cap));
+    HIP_TRY(hipMalloc(&h->sia_kpws, sizeof(float) * 9 * (size_t)h->rec_cap));
     *out = h;
     return SVO_OK;
 }
@@ -89,7 +87,6 @@ extern "C" int svo_handle_destroy(svo_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->ring);
-    (void)hipFree(h->sia_cache);
     (void)hipFree(h->sia_kpws);
     (void)hipFree(h->sia_rec);
     (void)hipFree(h->kf_one);
@@ -100,6 +97,12 @@ extern "C" int svo_handle_destroy(svo_handle* h) {
 extern "C" int svo_handle_set_stream(svo_handle* h, void* s) {
     if (!h) return fail(SVO_ERR_INVALID, "null handle");
     h->stream = reinterpret_cast<hipStream_t>(s);
+    return SVO_OK;
+}
+
+extern "C" int svo_handle_set_fast_solver(svo_handle* h, int on) {
+    if (!h) return fail(SVO_ERR_INVALID, "null handle");
+    h->exact_pinv = on == 0;
     return SVO_OK;
 }
 
@@ -137,6 +140,47 @@ static int stage_n(svo_handle* h, int n, int** d_n) { return stage<int>(h, n, d_
         if (!(h)) return fail(SVO_ERR_INVALID, "null handle");       \
         HIP_TRY(hipSetDevice((h)->device));                          \
     } while (0)
+
+extern "C" int svo_device_malloc(size_t bytes, void** out) {
+    if (!out) return fail(SVO_ERR_INVALID, "svo_device_malloc: null out");
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return SVO_OK;
+}
+extern "C" int svo_device_free(void* p) {
+    if (p) HIP_TRY(hipFree(p));
+    return SVO_OK;
+}
+extern "C" int svo_copy_to_device(svo_handle* h, void* dst, const void* src, size_t bytes) {
+    CHECK_H(h);
+    if (bytes == 0) return SVO_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SVO_OK;
+}
+extern "C" int svo_copy_to_host(svo_handle* h, void* dst, const void* src, size_t bytes) {
+    CHECK_H(h);
+    if (bytes == 0) return SVO_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SVO_OK;
+}
+extern "C" int svo_copy_image_to_device(svo_handle* h, void* dst, size_t dst_stride, const void* src,
+                                        size_t src_stride, size_t width, size_t height) {
+    CHECK_H(h);
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, src, src_stride, width, height, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_project_keypoints(svo_handle* h, const float* pose, const svo_kp3d* kps3d, int n,
+                                     const svo_camera_settings* cam, svo_kp2d* out) {
+    CHECK_H(h);
+    if (!pose || !cam || n < 0 || (n > 0 && (!kps3d || !out)))
+        return fail(SVO_ERR_INVALID, "svo_project_keypoints: bad arguments");
+    if (n > 0) launch_project(pose, kps3d, n, *cam, out, h->stream);
+    HIP_TRY(hipGetLastError());
+    return SVO_OK;
+}
 
 extern "C" int svo_build_pyramid(svo_handle* h, int n_levels, svo_image* levels) {
     CHECK_H(h);
@@ -212,7 +256,7 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     sa.n_ptr = d_n;
     sa.kps2d = kps2d; sa.kps3d = kps3d; sa.flags = flags;
     sa.pose_guess = pose_guess; sa.pose_out = pose_out; sa.cost_out = cost; sa.trace = trace;
-    sa.cache = h->sia_cache; sa.kp_ws = h->sia_kpws;
+    sa.kp_ws = h->sia_kpws;
     sa.rec_ws = h->sia_rec; sa.rec_cap = h->rec_cap;
     sa.dbg_H = dbg; sa.dbg_level = dbg_level;
     sa.cap = h->max_kps;
@@ -220,7 +264,8 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     SiaArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
-    launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->rec_cap, h->exact_pinv, h->stream);
+    if (!launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->rec_cap, h->exact_pinv, h->stream))
+        return fail(SVO_ERR_CAPACITY, "svo_sparse_align: %d keypoints exceed the workspaces", n);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -276,7 +321,8 @@ extern "C" int svo_reproj_gn(svo_handle* h, svo_kp2d* kps2d, const svo_kp3d* kps
     ReprojArgs* d;
     rc = stage(h, ra, &d);
     if (rc) return rc;
-    launch_reproj(d, 1, h->stream);
+    if (!launch_reproj(d, 1, n, h->stream))
+        return fail(SVO_ERR_CAPACITY, "svo_reproj_gn: %d keypoints do not fit LDS", n);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

@@ -180,7 +180,6 @@ struct Seq {
     float* klt_err = nullptr;
     uint8_t* klt_status = nullptr;
     float* disparity = nullptr;
-    float4* sia_cache = nullptr;
     float* sia_rec = nullptr;        // per-level alignment records (sia_prep_kernel)
     float* sia_kpws = nullptr;
     PoseMats* sia_mats = nullptr;    // rotation matrices of the aligned pose (sia_gn_kernel -> klt_track_kernel)
@@ -298,7 +297,7 @@ struct svo_group {
     size_t readback_bytes = 0;
     bool timing = false;
     bool failed = false;
-    int exact_pinv = 0;
+    int exact_pinv = 1;          // reference-order Gauss-Newton unless svo_ctx_set_fast_solver(ctx, 1)
     hipEvent_t ev[10] = {nullptr};
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
@@ -590,9 +589,8 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
         if ((rc = dev_alloc(c, &q.klt_err, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.klt_status, (size_t)c->cap))) return rc;
         if ((rc = dev_alloc(c, &q.disparity, (size_t)c->cap))) return rc;
-        if ((rc = dev_alloc(c, &q.sia_cache, (size_t)c->cap * 16))) return rc;
         if ((rc = dev_alloc(c, &q.sia_rec, sia_rec_ws_floats(*cam, c->rec_cap)))) return rc;
-        if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)(c->cap + 16) * 40))) return rc;
+        if ((rc = dev_alloc(c, &q.sia_kpws, (size_t)9 * c->rec_cap))) return rc;
         if ((rc = dev_alloc(c, &q.sia_mats, 1))) return rc;
         if ((rc = dev_alloc(c, &q.d_kfs, (size_t)c->max_kf))) return rc;
         if ((rc = dev_alloc(c, &q.det, (size_t)SVO_MAX_PYRAMID_LEVELS * c->max_cells))) return rc;
@@ -725,6 +723,18 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     const int B = c->B;
     const bool first = c->seqs[0].frame_id < 0;
     int rc;
+    // Sequences whose image pointers are NULL sit this step out (their state is untouched): a ctx
+    // can hold sequences of different lengths. The others are packed into the first M slots of
+    // every argument array, so the launches cover exactly them.
+    std::vector<int> act;
+    act.reserve(B);
+    for (int s = 0; s < B; s++)
+        if (left[s] && right[s]) act.push_back(s);
+        else if ((left[s] != nullptr) != (right[s] != nullptr))
+            return svo_set_error(SVO_ERR_INVALID, "svo_new_images: sequence %d has only one image", s);
+    const int M = (int)act.size();
+    if (first && M != B) return svo_set_error(SVO_ERR_INVALID, "svo_new_images: the first frame needs every sequence");
+    if (M == 0) return SVO_OK;
 #define SVO_MARK(i) do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[i], c->stream)); } while (0)
     auto hclock = wall0;
     auto hlap = [&](int i) {
@@ -751,8 +761,9 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             const uint8_t* const* src = side ? right : left;
             int s0 = 0;
             while (s0 < B) {
+                if (!src[s0]) { s0++; continue; }
                 int s1 = s0 + 1;
-                while (s1 < B && src[s1] == src[s1 - 1] + spacing) s1++;
+                while (s1 < B && src[s1] && src[s1] == src[s1 - 1] + spacing) s1++;
                 uint8_t* dst = c->d_stage_in + (size_t)(side * B + s0) * c->stage_frame_bytes;
                 if (s1 - s0 > 1) {
                     HIP_TRY(hipMemcpy2DAsync(dst, c->stage_frame_bytes, src[s0], spacing, spacing, s1 - s0,
@@ -764,13 +775,14 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             }
         }
     }
-    for (int s = 0; s < B; s++) {
+    for (int j = 0; j < M; j++) {
+        const int s = act[j];
         Seq& q = c->seqs[s];
         release_set(q, q.prev_set);
         q.prev_set = q.cur_set;
         if ((rc = acquire_set(c, q, &q.cur_set))) return rc;
         ImageSet* is = q.cur_set;
-        PyrArgs* hs = args_at<PyrArgs>(c, c->off_hs, s);
+        PyrArgs* hs = args_at<PyrArgs>(c, c->off_hs, j);
         std::memset(hs, 0, sizeof(*hs));
         hs->n_levels = c->cam.max_pyramid_levels;
         for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
@@ -781,14 +793,14 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         hs->src_left = ImgView{src_l, c->width, c->height, stride};
         hs->src_right = ImgView{src_r, c->width, c->height, stride};
         hs->dst_right = is->right;
-        PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, s);
+        PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, j);
         std::memset(lk, 0, sizeof(*lk));
         lk->n_levels = c->n_lk;
         for (int l = 0; l < c->n_lk; l++) lk->level[l] = is->lk[l];
     }
 
     if (!first) {
-        auto fill = [c](int s) {
+        auto fill = [c](int slot, int s) {
             Seq& q = c->seqs[s];
             FrameResult* dr = c->d_res + s;
             // predicted pose = kf.statePre (stereo_slam.cpp:183-192)
@@ -797,12 +809,12 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             for (int i = 0; i < 6; i++) guess[i] = q.pending ? q.kf.statePost[i] : q.kf.statePre[i];
             const float* d_guess = dargs_at<float>(c, c->off_guess, s * 8);
             // remove_outliers: previous set -> other set (becomes the frame's keypoints)
-            CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, s);
+            CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, slot);
             std::memset(ca, 0, sizeof(*ca));
             ca->src = q.kps[q.cur]; ca->dst = q.kps[q.cur ^ 1]; ca->mode = 0;
             q.cur ^= 1;
             const KpsDev& k = q.kps[q.cur];
-            SiaArgs* sa = args_at<SiaArgs>(c, c->off_sia, s);
+            SiaArgs* sa = args_at<SiaArgs>(c, c->off_sia, slot);
             std::memset(sa, 0, sizeof(*sa));
             for (int l = 0; l < c->cam.max_pyramid_levels; l++) {
                 sa->prev[l] = q.prev_set->left[l];
@@ -810,11 +822,11 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             }
             sa->cam = c->cam; sa->n_ptr = k.n; sa->kps2d = k.kps2d; sa->kps3d = k.kps3d; sa->flags = k.flags;
             sa->pose_guess = d_guess; sa->pose_out = dr->pose_sia; sa->cost_out = &dr->sia_cost;
-            sa->trace = dr->sia_trace; sa->cache = q.sia_cache; sa->kp_ws = q.sia_kpws;
+            sa->trace = dr->sia_trace; sa->kp_ws = q.sia_kpws;
             sa->rec_ws = q.sia_rec; sa->rec_cap = c->rec_cap;
             sa->mats_out = q.sia_mats;
             sa->dbg_H = nullptr; sa->dbg_level = -1; sa->cap = c->cap; sa->exact_pinv = c->exact_pinv;
-            KltArgs* ka = args_at<KltArgs>(c, c->off_klt, s);
+            KltArgs* ka = args_at<KltArgs>(c, c->off_klt, slot);
             std::memset(ka, 0, sizeof(*ka));
             ka->kfs = q.d_kfs; ka->kf_id = k.kf_id; ka->n_cur = c->n_lk;
             for (int l = 0; l < c->n_lk; l++) ka->cur[l] = q.cur_set->lk[l];
@@ -822,19 +834,19 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             ka->err = q.klt_err; ka->win = c->cam.window_size_opt_flow;
             ka->proj_pose = dr->pose_sia; ka->proj_mats = q.sia_mats; ka->kps3d = k.kps3d; ka->proj_out = k.kps2d;
             ka->kp_index = k.kp_index; ka->ref_out = nullptr; ka->cam = c->cam;
-            ReprojArgs* ra = args_at<ReprojArgs>(c, c->off_rp, s);
+            ReprojArgs* ra = args_at<ReprojArgs>(c, c->off_rp, slot);
             std::memset(ra, 0, sizeof(*ra));
             ra->cam = c->cam; ra->n_ptr = k.n; ra->kps2d = k.kps2d; ra->kps3d = k.kps3d; ra->flags = k.flags;
             ra->tracked = q.tracked; ra->err = q.klt_err; ra->pose_in = dr->pose_sia;
             ra->pose_out = dr->pose_refined; ra->cost_out = &dr->reproj_cost; ra->trace = &dr->reproj_trace;
             ra->exact_pinv = c->exact_pinv;
-            SsdArgs* ss = args_at<SsdArgs>(c, c->off_ssd, s);
+            SsdArgs* ss = args_at<SsdArgs>(c, c->off_ssd, slot);
             std::memset(ss, 0, sizeof(*ss));
             ss->left = q.cur_set->left[0]; ss->right = q.cur_set->right; ss->n_ptr = k.n;
             ss->kps2d = k.kps2d; ss->disparity = q.disparity;
             ss->win = c->cam.window_size_depth_calculator; ss->search_x = c->cam.search_x;
             ss->search_y = c->cam.search_y; ss->clamp_half = 1;
-            FilterArgs* fa = args_at<FilterArgs>(c, c->off_filt, s);
+            FilterArgs* fa = args_at<FilterArgs>(c, c->off_filt, slot);
             std::memset(fa, 0, sizeof(*fa));
             fa->cam = c->cam; fa->n_ptr = k.n; fa->frame_pose = dr->pose_refined;
             fa->kps2d = k.kps2d; fa->kps3d = k.kps3d; fa->flags = k.flags;
@@ -844,17 +856,17 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             fa->do_outlier_check = 1; fa->do_update = 1; fa->do_flags = 1; fa->do_reproject = 1;
             fa->width = c->width; fa->height = c->height; fa->inside_count = c->d_inside + s;
         };
-        for (int s = 0; s < B; s++) fill(s);   // ~20 us for 256 sequences: not worth waking the pool
+        for (int j = 0; j < M; j++) fill(j, act[j]);   // ~20 us for 256 sequences: not worth waking the pool
     }
     hlap(0);   // argument blocks
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, first ? c->args_bytes : c->frame_args_bytes,
                            hipMemcpyHostToDevice, c->stream));
-    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), B, c->width, c->height, true, c->stream);
+    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, true, c->stream);
     {
         int w = c->width, h = c->height;
         for (int l = 0; l + 1 < c->n_lk; l++) {
             w = (w + 1) / 2; h = (h + 1) / 2;
-            launch_pyr_down(dargs_at<PyrArgs>(c, c->off_lk), B, l, w, h, c->stream);
+            launch_pyr_down(dargs_at<PyrArgs>(c, c->off_lk), M, l, w, h, c->stream);
         }
     }
     std::vector<int> need(B, 0);
@@ -867,22 +879,24 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         if ((rc = enqueue_keyframes(c, need, true))) return rc;
     } else {
         SVO_MARK(1);
-        launch_compact(dargs_at<CompactArgs>(c, c->off_compact), B, c->cap, c->stream);
+        launch_compact(dargs_at<CompactArgs>(c, c->off_compact), M, c->cap, c->stream);
         SVO_MARK(2);
         // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the
         // grids and the alignment kernel's LDS working set
         int grid_n = 1;
-        for (int s = 0; s < B; s++) grid_n = std::max(grid_n, c->seqs[s].n_host);
+        for (int j = 0; j < M; j++) grid_n = std::max(grid_n, c->seqs[act[j]].n_host);
         grid_n = std::min(grid_n, c->cap);
-        launch_sia(dargs_at<SiaArgs>(c, c->off_sia), B, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream);
+        if (!launch_sia(dargs_at<SiaArgs>(c, c->off_sia), M, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream))
+            return svo_set_error(SVO_ERR_CAPACITY, "sparse alignment: %d keypoints exceed the workspaces", grid_n);
         SVO_MARK(3);
-        launch_klt(dargs_at<KltArgs>(c, c->off_klt), B, grid_n, c->cam.window_size_opt_flow, c->stream);
+        launch_klt(dargs_at<KltArgs>(c, c->off_klt), M, grid_n, c->cam.window_size_opt_flow, c->stream);
         SVO_MARK(4);
-        launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), B, c->stream);
+        if (!launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), M, grid_n, c->stream))
+            return svo_set_error(SVO_ERR_CAPACITY, "reprojection GN: %d keypoints do not fit LDS", grid_n);
         SVO_MARK(5);
-        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), B, grid_n, c->stream);
+        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->stream);
         SVO_MARK(6);
-        launch_filter(dargs_at<FilterArgs>(c, c->off_filt), B, c->stream);
+        launch_filter(dargs_at<FilterArgs>(c, c->off_filt), M, c->stream);
         SVO_MARK(7);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_inside, c->d_inside, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
@@ -894,7 +908,8 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         // KeyFrameManager::keyframe_needed (keyframe_manager.cpp:66-72)
         const int max_keypoints = (c->width / c->cam.grid_width) * (c->height / c->cam.grid_height);
         bool any = false;
-        for (int s = 0; s < B; s++) {
+        for (int j = 0; j < M; j++) {
+            const int s = act[j];
             need[s] = (double)c->h_inside[s] < 0.66 * max_keypoints ? 1 : 0;
             any = any || need[s];
         }
@@ -920,7 +935,8 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
 
     // ---- host bookkeeping (stereo_slam.cpp:250-270); the pose filter itself is deferred
     int overflow_seq = -1;
-    for (int s = 0; s < B; s++) {
+    for (int j = 0; j < M; j++) {
+        const int s = act[j];
         Seq& q = c->seqs[s];
         const FrameResult& r = c->h_res[s];
         const double ts = (double)time_stamps[s];
@@ -1300,6 +1316,9 @@ extern "C" int svo_new_image(svo_ctx* c, const uint8_t* left, int left_stride, c
     if (!c || c->B != 1) return svo_set_error(SVO_ERR_INVALID, "svo_new_image needs a 1-sequence ctx");
     return grp_new_image(c->workers[0]->g, left, left_stride, right, right_stride, width, height, time_stamp);
 }
+
+extern "C" int svo_ctx_set_exact_pinv(svo_ctx* c, int on);
+extern "C" int svo_ctx_set_fast_solver(svo_ctx* c, int on) { return svo_ctx_set_exact_pinv(c, on == 0); }
 
 extern "C" int svo_ctx_set_exact_pinv(svo_ctx* c, int on) {
     if (!c) return svo_set_error(SVO_ERR_INVALID, "bad ctx");

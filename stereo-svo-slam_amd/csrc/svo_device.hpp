@@ -16,9 +16,24 @@
 
 namespace svo {
 
+// Pointers that reach a kernel through an argument block in memory are generic to the compiler:
+// it emits flat_load / flat_store and must drain vmcnt AND lgkmcnt around every LDS access next to
+// them. Device code therefore casts them to the global address space where they are used
+// (G(ptr), ImgView::g()): global_load / global_store with counted waits, scalar loads for
+// wave-uniform values.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SVO_GP(T) __attribute__((address_space(1))) T*
+#else
+#define SVO_GP(T) T*      /* host pass: device functions are only parsed */
+#endif
+template <class T>
+__device__ __forceinline__ SVO_GP(T) G(T* p) { return (SVO_GP(T))p; }
+
 struct ImgView {
     const uint8_t* data;
     int w, h, stride;
+    __device__ __forceinline__ SVO_GP(const uint8_t) g() const { return (SVO_GP(const uint8_t))data; }
+    __device__ __forceinline__ SVO_GP(uint8_t) gw() const { return (SVO_GP(uint8_t))data; }
 };
 
 __host__ __device__ inline ImgView make_view(const svo_image& im) {
@@ -103,6 +118,31 @@ __device__ inline long long wave_sum_i32_to_i64(int v) {
     const int lo = wave_sum_dpp_i(v & 0xFFFF);
     const int hi = wave_sum_dpp_i(v >> 16);
     return (long long)hi * 65536LL + (long long)lo;
+}
+
+// ------------------------------------------------- reference-order sums
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// sequential sum of buf[0..n) continuing from s. buf is in LDS, zero padded to a multiple of 128
+// floats (adding the zeros is exact): every block of 128 is 32 ds_read_b128 issued back to back
+// and one chain of 128 adds behind them, so the add chain, not the LDS, sets the pace.
+__device__ inline float ordered_sum(const float* buf, int n, float s) {
+    const SVO_LDS(v4f)* p = (const SVO_LDS(v4f)*)buf;
+    for (int b = 0; b < n; b += 128, p += 32) {
+        v4f v[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) v[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < 32; j++) { s += v[j].x; s += v[j].y; s += v[j].z; s += v[j].w; }
+    }
+    return s;
+}
+
+// sequential sum over the 64 lanes of a wave, lane 0 first (v_readlane + add: no LDS), continuing from s
+__device__ inline float ordered_wave_sum(float v, float s) {
+#pragma unroll
+    for (int j = 0; j < 64; j++) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+    return s;
 }
 
 // ------------------------------------------------------------- rotations

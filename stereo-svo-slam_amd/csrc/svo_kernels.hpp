@@ -39,8 +39,7 @@ struct SiaArgs {
     svo_gn_trace* trace;          // [SVO_MAX_PYRAMID_LEVELS] or null
     float* rec_ws;                // workspace [levels used][68][rec_cap]: per-level records of sia_prep_kernel
     int rec_cap;                  // keypoint capacity (row length) of rec_ws, multiple of 4
-    float4* cache;                // workspace [cap*16]: per (kp,px) {gx, gy, ps_prev, i1_prev} (sia_big only)
-    float* kp_ws;                 // workspace [(cap+16)*40] floats: per-keypoint arrays when they do not fit LDS
+    float* kp_ws;                 // workspace [9][rec_cap] floats: per-keypoint values of sets that do not fit LDS
     float* dbg_H;                 // optional [36+6+6]: H, b, step of the first get_gradient of `dbg_level`
     int dbg_level;
     int cap;
@@ -49,8 +48,8 @@ struct SiaArgs {
 };
 // n_bound: upper bound of the keypoint counts of the launch's sequences (chooses the workgroup
 // shape); rec_cap: SiaArgs::rec_cap of every block; exact: the value of SiaArgs::exact_pinv in every block (sizes the LDS staging)
-void launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
-                int height, int n_bound, int rec_cap, int exact, hipStream_t stream);
+bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
+                int height, int n_bound, int rec_cap, int exact, hipStream_t stream);   // false: capacity
 size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap);   // size of SiaArgs::rec_ws
 
 // --------------------------------------------------------------------- KLT
@@ -105,7 +104,12 @@ struct ReprojArgs {
     svo_gn_trace* trace;          // [1] or null
     int exact_pinv;
 };
-void launch_reproj(const ReprojArgs* d_args, int batch, hipStream_t stream);
+bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t stream);   // false: too many keypoints
+
+// project_keypoints (src/lib/transform_keypoints.cpp:11-48) as a stage of its own (the tracker
+// fuses it into klt_track_kernel / filter_update_kernel)
+void launch_project(const float* pose, const svo_kp3d* kps3d, int n, const svo_camera_settings& cam,
+                    svo_kp2d* out, hipStream_t stream);
 
 // ------------------------------------------------------------ depth filter
 struct SsdArgs {

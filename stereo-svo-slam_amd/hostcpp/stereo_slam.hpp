@@ -6,46 +6,9 @@
 // against this header unchanged.
 #pragma once
 
-#include <cstdint>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "../../include/svo_hip.h"
-
-#if defined(__has_include)
-#if __has_include(<opencv2/core.hpp>)
-#include <opencv2/core.hpp>
-#define SVO_FACADE_HAVE_OPENCV 1
-#endif
-#endif
+#include "stereo_slam_types.hpp"
 
 namespace svo_amd {
-
-using CameraSettings = svo_camera_settings;   // same field order as the reference
-using KeyPoint2d = svo_kp2d;
-using KeyPoint3d = svo_kp3d;
-using Pose = svo_pose;
-using KeyPointInformation = svo_kp_info;
-
-struct KeyPoints {
-    std::vector<KeyPoint2d> kps2d;
-    std::vector<KeyPoint3d> kps3d;
-    std::vector<KeyPointInformation> info;
-};
-
-struct Frame {
-    uint64_t id = 0;
-    Pose pose{};
-    KeyPoints kps;
-    double time_stamp = 0;
-};
-struct KeyFrame : Frame {};
-
-struct Image8 {            // CV_8U single channel view
-    const uint8_t* data;
-    int cols, rows, step;
-};
 
 class StereoSlam {
 public:
@@ -55,18 +18,22 @@ public:
     StereoSlam(const StereoSlam&) = delete;
     StereoSlam& operator=(const StereoSlam&) = delete;
 
+    // svo_ctx_set_fast_solver: off (default) = the reference's Gauss-Newton arithmetic, bit for bit
+    void set_fast_solver(bool on) { fast = on; if (ctx) check(svo_ctx_set_fast_solver(ctx, on ? 1 : 0)); }
+
     // void new_image(const cv::Mat& left, const cv::Mat& right, const float time_stamp)
     void new_image(const Image8& left, const Image8& right, const float time_stamp) {
-        if (!ctx) check(svo_ctx_create(&camera_settings, left.cols, left.rows, 1, device, &ctx));
+        if (!ctx) {
+            check(svo_ctx_create(&camera_settings, left.cols, left.rows, 1, device, &ctx));
+            if (fast) check(svo_ctx_set_fast_solver(ctx, 1));
+        }
         check(svo_new_image(ctx, left.data, left.step, right.data, right.step, left.cols, left.rows,
                             time_stamp));
         last_ts = time_stamp;
     }
 #ifdef SVO_FACADE_HAVE_OPENCV
     void new_image(const cv::Mat& left, const cv::Mat& right, const float time_stamp) {
-        CV_Assert(left.type() == CV_8U && right.type() == CV_8U);
-        new_image(Image8{left.data, left.cols, left.rows, (int)left.step},
-                  Image8{right.data, right.cols, right.rows, (int)right.step}, time_stamp);
+        new_image(view_of(left), view_of(right), time_stamp);
     }
 #endif
 
@@ -77,7 +44,9 @@ public:
         frame.kps.kps2d.resize(n); frame.kps.kps3d.resize(n); frame.kps.info.resize(n);
         check(svo_get_frame_keypoints(ctx, 0, frame.kps.kps2d.data(), frame.kps.kps3d.data(),
                                       frame.kps.info.data(), n, &n));
-        check(svo_get_pose(ctx, 0, &frame.pose.x));
+        Pose p{};
+        check(svo_get_pose(ctx, 0, &p.x));
+        frame.pose.set_pose(p);
         svo_frame_stats st;
         check(svo_get_frame_stats(ctx, 0, &st));
         frame.id = (uint64_t)st.frame_id;
@@ -113,21 +82,19 @@ public:
 private:
     void read_keyframe(int id, KeyFrame& kf) {
         int n = 0;
-        check(svo_get_keyframe(ctx, 0, id, nullptr, nullptr, nullptr, &kf.pose.x, 0, &n));
+        Pose p{};
+        check(svo_get_keyframe(ctx, 0, id, nullptr, nullptr, nullptr, &p.x, 0, &n));
         kf.kps.kps2d.resize(n); kf.kps.kps3d.resize(n); kf.kps.info.resize(n);
         check(svo_get_keyframe(ctx, 0, id, kf.kps.kps2d.data(), kf.kps.kps3d.data(),
-                               kf.kps.info.data(), &kf.pose.x, n, &n));
+                               kf.kps.info.data(), &p.x, n, &n));
+        kf.pose.set_pose(p);
         kf.id = (uint64_t)id;
-    }
-    // the reference's methods return void and print diagnostics; a failing HIP call has no
-    // analogue there, so it is surfaced as an exception instead of being swallowed
-    static void check(int rc) {
-        if (rc != SVO_OK) throw std::runtime_error(std::string("libsvo_hip: ") + svo_last_error());
     }
     const CameraSettings camera_settings;
     int device;
     svo_ctx* ctx = nullptr;
     double last_ts = 0;
+    bool fast = false;
 };
 
 }  // namespace svo_amd

@@ -25,6 +25,9 @@ SYMBOLS = (
     "svo_get_frame_keypoints", "svo_get_keyframe_count", "svo_get_keyframe",
     "svo_get_trajectory", "svo_update_pose", "svo_get_frame_stats", "svo_ctx_enable_timing",
     "svo_get_totals", "svo_handle_set_exact_pinv", "svo_ctx_set_exact_pinv",
+    "svo_handle_set_fast_solver", "svo_ctx_set_fast_solver",
+    "svo_device_malloc", "svo_device_free", "svo_copy_to_device", "svo_copy_to_host",
+    "svo_copy_image_to_device", "svo_project_keypoints",
 )
 
 
@@ -116,8 +119,13 @@ class Handle:
     def synchronize(self):
         _check(lib().svo_handle_synchronize(self._h))
 
+    def set_fast_solver(self, on=True):
+        """svo_handle_set_fast_solver: off (default) = the reference's row-by-row normal equations +
+        SVD pseudo-inverse; on = tree sums + LDL^T."""
+        _check(lib().svo_handle_set_fast_solver(self._h, int(on)))
+
     def set_exact_pinv(self, on=True):
-        _check(lib().svo_handle_set_exact_pinv(self._h, int(on)))
+        self.set_fast_solver(not on)
 
     def close(self):
         if getattr(self, "_h", None) and _LIB is not None:
@@ -171,6 +179,14 @@ class Handle:
             n, C.byref(cam), _ptr(pose_guess), _ptr(pose_out), _ptr(cost), _ptr(trace), _ptr(dbg),
             dbg_level))
         return pose_out, cost, trace, dbg
+
+    # -- A3 ---------------------------------------------------------------
+    def project_keypoints(self, pose, kps3d, cam):
+        """project_keypoints (src/lib/transform_keypoints.cpp:11-48): pose [6] and kps3d device tensors."""
+        n = kps3d.shape[0]
+        out = torch.zeros((n, 2), dtype=torch.float32, device=kps3d.device)
+        _check(lib().svo_project_keypoints(self._h, _ptr(pose), _ptr(kps3d), n, C.byref(cam), _ptr(out)))
+        return out
 
     # -- B2 ---------------------------------------------------------------
     def klt_track(self, prev_lk, cur_lk, prev_pts, cur_pts, win):

@@ -44,6 +44,39 @@ def sequence_ids(rank, world, seqs_per_rank):
     return list(range(rank * seqs_per_rank, (rank + 1) * seqs_per_rank))
 
 
+def assign_longest_first(lengths, n_ranks):
+    """Static longest-first assignment of whole sequences to ranks (a sequence cannot be
+    split, frame t needs frame t-1): sequences by decreasing length, each to the rank with the least
+    work so far. Returns one list of sequence indices per rank (ranks may stay empty: six EuRoC
+    sequences on eight GPUs keep six busy)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    load = [0] * n_ranks
+    out = [[] for _ in range(n_ranks)]
+    for i in order:
+        r = min(range(n_ranks), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += lengths[i]
+    return out
+
+
+def play_unequal(slam, frames_of, lengths, time_of=lambda k: k / 20.0):
+    """Drive the sequences of one ctx to their own ends: at step k every sequence that still has a
+    frame gets it, the others sit the step out (svo_new_images with NULL pointers). frames_of(s, k)
+    -> (left, right). Returns the number of sequence-frames processed."""
+    done = 0
+    for k in range(max(lengths) if lengths else 0):
+        L, R = [], []
+        for s, n in enumerate(lengths):
+            if k < n:
+                l, r = frames_of(s, k)
+                L.append(l); R.append(r)
+                done += 1
+            else:
+                L.append(None); R.append(None)
+        slam.new_images(L, R, [time_of(k)] * len(lengths))
+    return done
+
+
 def _sync(device):
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)

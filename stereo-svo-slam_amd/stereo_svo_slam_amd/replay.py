@@ -6,10 +6,18 @@ and of the evaluation scripts test/extract_fps.py:26-34 / test/extract_extremas.
 Host bookkeeping only; every frame goes through StereoSlam.new_image (libsvo_hip.so).
 
     python -m stereo_svo_slam_amd.replay --synthetic euroc --frames 100 -t traj.csv
-    python -m stereo_svo_slam_amd.replay --settings EuRoC.yaml --pairs 'seq/%06d_left.png,seq/%06d_right.png' -t traj.csv
+    python -m stereo_svo_slam_amd.replay --settings EuRoC.yaml --euroc /data/MH_02_easy/mav0/ -t traj.csv
+    python -m stereo_svo_slam_amd.replay --settings Blender.yaml --sbs 'frames/%06d.png' -t traj.csv
+    python -m stereo_svo_slam_amd.replay --settings EuRoC.yaml --pairs 'seq/%06d_left.png,seq/%06d_right.png'
+
+Inputs follow the reference's conventions (the library's `left` is the physically RIGHT camera):
+EurocInput (src/app/euroc_input.cpp:48-70,100-105), VideoInput (src/app/video_input.cpp:35-36).
+With $SVO_DATA set (a EuRoC `mav0/` directory, or a directory of side-by-side frames) and no
+explicit input that data is used; otherwise the seeded synthetic sequence.
 """
 import argparse
 import math
+import os
 import re
 import time
 
@@ -50,6 +58,135 @@ def read_settings(path):
             if m2:
                 out["width" if "width" in m2.group(1) else "height"] = int(m2.group(3))
     return out
+
+
+def read_matrix(path, key):
+    """A `key: !!opencv-matrix` entry of a cv::FileStorage YAML (rows, cols, data) as float64 array,
+    or None (LEFT.K, LEFT.D, LEFT.R, LEFT.P ... of src/app/EuRoC.yaml)."""
+    txt = open(path).read()
+    m = re.search(re.escape(key) + r"\s*:\s*!!opencv-matrix\s*rows:\s*(\d+)\s*cols:\s*(\d+)\s*dt:\s*\w+\s*data:\s*\[([^\]]*)\]",
+                  txt, re.S)
+    if not m:
+        return None
+    return np.array([float(v) for v in m.group(3).replace("\n", " ").split(",")], np.float64).reshape(
+        int(m.group(1)), int(m.group(2)))
+
+
+def read_scalar(path, key, default=0):
+    m = re.search(r"^" + re.escape(key) + r"\s*:\s*([-+0-9.eE]+)", open(path).read(), re.M)
+    return float(m.group(1)) if m else default
+
+
+def undistort_rectify_map(K, D, R, P, size):
+    """cv::initUndistortRectifyMap(K, D, R, P[:3,:3], size, CV_32F): for every pixel of the rectified
+    image the position in the raw image (map_x, map_y), 5-coefficient Brown model."""
+    w, h = size
+    iR = np.linalg.inv(np.asarray(P, np.float64)[:3, :3] @ np.asarray(R, np.float64))
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    pts = np.stack([u, v, np.ones_like(u)], -1) @ iR.T
+    x, y = pts[..., 0] / pts[..., 2], pts[..., 1] / pts[..., 2]
+    d = list(np.ravel(D)) + [0.0] * 5
+    k1, k2, p1, p2, k3 = d[:5]
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * 2 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + p2 * 2 * x * y
+    K = np.asarray(K, np.float64)
+    return (K[0, 0] * xd + K[0, 2]).astype(np.float32), (K[1, 1] * yd + K[1, 2]).astype(np.float32)
+
+
+def remap_linear(img, map_x, map_y):
+    """cv::remap(img, ., map_x, map_y, INTER_LINEAR) with a constant 0 border, 8-bit."""
+    h, w = img.shape
+    x0 = np.floor(map_x).astype(np.int64)
+    y0 = np.floor(map_y).astype(np.int64)
+    ax, ay = map_x - x0, map_y - y0
+    src = np.pad(img.astype(np.float32), 1)
+
+    def at(yy, xx):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        return np.where(ok, src[np.clip(yy, -1, h) + 1, np.clip(xx, -1, w) + 1], 0.0)
+
+    v = (at(y0, x0) * (1 - ax) * (1 - ay) + at(y0, x0 + 1) * ax * (1 - ay) +
+         at(y0 + 1, x0) * (1 - ax) * ay + at(y0 + 1, x0 + 1) * ax * ay)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def _gray(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(path).convert("L")))
+
+
+class EurocInput:
+    """EurocInput (src/app/euroc_input.cpp): `image_path` is the mav0/ directory. cam0/data.csv lists
+    time stamps [ns] and file names; the library's `right` image is cam0 rectified with the LEFT.*
+    calibration of the settings file, `left` is cam1 rectified with RIGHT.* (:69-70, :100-101); time
+    stamps are seconds since the first frame as float (:104-110)."""
+
+    def __init__(self, image_path, settings):
+        self.right_images, self.left_images, self.timestamps = [], [], []
+        t0 = None
+        with open(os.path.join(image_path, "cam0", "data.csv")) as fh:
+            for line in fh:
+                line = line.strip()
+                if not line or line.startswith("#"):
+                    continue
+                stamp, name = line.split(",")[0], line.split(",")[-1].strip()
+                self.right_images.append(os.path.join(image_path, "cam0", "data", name))
+                self.left_images.append(os.path.join(image_path, "cam1", "data", name))
+                t = float(stamp) / 1.0e9
+                t0 = t if t0 is None else t0
+                self.timestamps.append(np.float32(t - t0))
+        self.maps_l = self.maps_r = None
+        mats = {k: read_matrix(settings, k) for k in ("LEFT.K", "LEFT.D", "LEFT.R", "LEFT.P",
+                                                     "RIGHT.K", "RIGHT.D", "RIGHT.R", "RIGHT.P")}
+        if all(v is not None for v in mats.values()):
+            size_l = (int(read_scalar(settings, "LEFT.width")), int(read_scalar(settings, "LEFT.height")))
+            size_r = (int(read_scalar(settings, "RIGHT.width")), int(read_scalar(settings, "RIGHT.height")))
+            self.maps_l = undistort_rectify_map(mats["LEFT.K"], mats["LEFT.D"], mats["LEFT.R"], mats["LEFT.P"], size_l)
+            self.maps_r = undistort_rectify_map(mats["RIGHT.K"], mats["RIGHT.D"], mats["RIGHT.R"], mats["RIGHT.P"], size_r)
+
+    def __len__(self):
+        return len(self.left_images)
+
+    def read(self, k):
+        """(left, right, time_stamp) in the library's naming."""
+        cam0, cam1 = _gray(self.right_images[k]), _gray(self.left_images[k])
+        if self.maps_l is not None:
+            cam0 = remap_linear(cam0, *self.maps_l)      # right <- remap(cam0, M1l, M2l)
+            cam1 = remap_linear(cam1, *self.maps_r)      # left  <- remap(cam1, M1r, M2r)
+        return cam1, cam0, float(self.timestamps[k])
+
+
+class SideBySideInput:
+    """VideoInput (src/app/video_input.cpp:25-45) on decoded frames: every image holds both cameras
+    side by side; `right` is the LEFT half, `left` the RIGHT half; time stamps advance by 1/fps from
+    1/fps."""
+
+    def __init__(self, pattern, n_frames, fps=30.0):
+        self.pattern, self.n, self.fps = pattern, n_frames, fps
+
+    def __len__(self):
+        return self.n
+
+    def read(self, k):
+        img = _gray(self.pattern % k)
+        w = img.shape[1] // 2
+        right = np.ascontiguousarray(img[:, :w])
+        left = np.ascontiguousarray(img[:, w:2 * w])
+        return left, right, (k + 1) / self.fps
+
+
+# END_MEASUREMENT names of the reference (src/lib/stereo_slam.cpp:66-86,140,227,235;
+# src/lib/pose_refinement.cpp:120) over the stage times of svo_frame_stats (HIP events)
+def time_trace_lines(stats):
+    st = list(stats.stage_ms)
+    lines = [("Create pyramid", st[0]), ("estimator", st[2]), ("REFINEMENT: Optical flow", st[3]),
+             ("pose refinement", st[3] + st[4]), ("Filter update", st[5] + st[6])]
+    if stats.is_keyframe:
+        lines.append(("Create new keyframe", st[7]))
+    lines.append(("Stereo SLAM", sum(st)))
+    return [f"{name} took: {ms:.4f}ms" for name, ms in lines]
 
 
 def _rodrigues(r):
@@ -116,17 +253,23 @@ def error_report(test_rows, reference_rows):
 class Replay:
     """process_image loop: only the time inside new_image is accumulated (slam_app.cpp:186-190)."""
 
-    def __init__(self, settings, device=0):
+    def __init__(self, settings, device=0, time_trace=False, exact=False):
         self.settings = settings
         self.slam = StereoSlam(settings, device=device)
+        self.slam.set_exact_pinv(exact)
         self.cumulative = []
         self._t = 0.0
+        self.time_trace = time_trace
+        if time_trace:
+            self.slam.enable_timing(True)
 
     def feed(self, left, right, time_stamp):
         t0 = time.perf_counter()
         self.slam.new_image(left, right, time_stamp)
         self._t += time.perf_counter() - t0
         self.cumulative.append(self._t)
+        if self.time_trace:                       # like PRINT_TIME_TRACE of the reference
+            print("\n".join(time_trace_lines(self.slam.stats())))
 
     def rows(self):
         traj = self.slam.get_trajectory()
@@ -148,6 +291,10 @@ def main(argv=None):
     ap.add_argument("--settings", help="cv::FileStorage YAML with the Camera.* keys")
     ap.add_argument("--synthetic", choices=sorted(synth.CONFIGS), help="seeded synthetic sequence")
     ap.add_argument("--pairs", help="'left_%%06d.png,right_%%06d.png': the library's left / right images")
+    ap.add_argument("--euroc", help="EuRoC mav0/ directory (cam0, cam1): EurocInput conventions")
+    ap.add_argument("--sbs", help="'frames/%%06d.png' side-by-side frames: VideoInput conventions")
+    ap.add_argument("--time-trace", action="store_true", help="print '<stage> took: X ms' per frame (reference names)")
+    ap.add_argument("--exact", action="store_true", help="reference-order mode of the Gauss-Newton kernels")
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--rate", type=float, default=20.0, help="frames per second of the time stamps")
@@ -156,7 +303,22 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     gt = None
-    if args.synthetic:
+    data = os.environ.get("SVO_DATA")
+    if data and not (args.synthetic or args.pairs or args.euroc or args.sbs):
+        if os.path.exists(os.path.join(data, "cam0", "data.csv")):
+            args.euroc = data
+        else:
+            args.sbs = os.path.join(data, "%06d.png")
+    if args.euroc and args.settings:
+        settings = read_settings(args.settings)
+        src = EurocInput(args.euroc, args.settings)
+        n = min(args.frames, len(src))
+        frames = (src.read(k) for k in range(n))
+    elif args.sbs and args.settings:
+        settings = read_settings(args.settings)
+        src = SideBySideInput(args.sbs, args.frames, args.rate)
+        frames = (src.read(k) for k in range(args.frames))
+    elif args.synthetic:
         cfg, L, R, gt, ts = synth.make_sequence(args.synthetic, args.frames, args.seed, device="cpu")
         settings = read_settings(args.settings) if args.settings else cfg
         frames = ((L[k].numpy(), R[k].numpy(), float(ts[k])) for k in range(args.frames))
@@ -164,8 +326,8 @@ def main(argv=None):
         settings = read_settings(args.settings)
         frames = ((*_load_pair(args.pairs, k), k / args.rate) for k in range(args.frames))
     else:
-        ap.error("give --synthetic or --settings with --pairs")
-    rp = Replay(settings, args.device)
+        ap.error("give --synthetic, or --settings with --euroc / --sbs / --pairs (or $SVO_DATA)")
+    rp = Replay(settings, args.device, args.time_trace, args.exact)
     for left, right, t in frames:
         rp.feed(left, right, t)
     rows = rp.rows()

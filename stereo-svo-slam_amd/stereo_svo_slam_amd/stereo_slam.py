@@ -82,21 +82,32 @@ class StereoSlamBatch:
         except Exception:
             pass
 
+    def set_fast_solver(self, on=True):
+        """svo_ctx_set_fast_solver: off (default) = reference-order Gauss-Newton (bit-exact traces);
+        on = tree sums + LDL^T solve."""
+        self._fast = bool(on)
+        if self._ctx:
+            _check(lib().svo_ctx_set_fast_solver(self._ctx, int(on)))
+
     def set_exact_pinv(self, on=True):
-        _check(lib().svo_ctx_set_exact_pinv(self._ctx, int(on)))
+        self.set_fast_solver(not on)
 
     def enable_timing(self, on=True):
         _check(lib().svo_ctx_enable_timing(self._ctx, int(on)))
 
     def new_images(self, lefts, rights, time_stamps):
-        """lefts/rights: per sequence a uint8 [H, W] numpy array (host) or torch CUDA tensor."""
+        """lefts/rights: per sequence a uint8 [H, W] numpy array (host) or torch CUDA tensor; None for
+        a sequence that has no frame at this step (it sits the step out: sequences of a ctx may have
+        different lengths)."""
         assert len(lefts) == self.n and len(rights) == self.n
-        on_dev = isinstance(lefts[0], torch.Tensor)
+        on_dev = isinstance(next(x for x in lefts if x is not None), torch.Tensor)
         ptrs_l = (C.c_void_p * self.n)()
         ptrs_r = (C.c_void_p * self.n)()
         keep = []
         stride = None
         for s in range(self.n):
+            if lefts[s] is None:
+                continue
             for arr, dst in ((lefts[s], ptrs_l), (rights[s], ptrs_r)):
                 if on_dev:
                     assert arr.is_cuda and arr.dtype == torch.uint8 and arr.stride(1) == 1
@@ -120,9 +131,12 @@ class StereoSlamBatch:
         the GPU (SVO_MEM_DEVICE) or all in host memory (SVO_MEM_HOST; pinned for full PCIe rate)."""
         ptrs_l = (C.c_void_p * self.n)()
         ptrs_r = (C.c_void_p * self.n)()
-        stride = lefts[0].stride(0)
-        on_dev = lefts[0].is_cuda
+        some = next(x for x in lefts if x is not None)
+        stride = some.stride(0)
+        on_dev = some.is_cuda
         for s in range(self.n):
+            if lefts[s] is None:                            # the sequence sits this step out
+                continue
             for arr, dst in ((lefts[s], ptrs_l), (rights[s], ptrs_r)):
                 assert arr.is_cuda == on_dev and arr.dtype == torch.uint8 and arr.stride(1) == 1
                 assert tuple(arr.shape) == (self.height, self.width) and arr.stride(0) == stride
@@ -225,4 +239,6 @@ class StereoSlam(StereoSlamBatch):
             cam, device = self._pending
             h, w = left.shape
             super().__init__(cam, w, h, 1, device)
+            if getattr(self, "_fast", False):
+                self.set_fast_solver(True)
         self.new_images([left], [right], [time_stamp])

@@ -87,8 +87,8 @@ def trajectory(n_frames, seed=0, scale=1.0):
 def _texture(rng, size=1024):
     t = np.full((size, size), 128.0, np.float32)
     for s, a in ((128, 28.0), (64, 26.0), (32, 24.0), (16, 20.0), (8, 14.0), (4, 8.0)):
-        t += np.kron(rng.uniform(-a, a, (size // s, size // s)).astype(np.float32),
-                     np.ones((s, s), np.float32))
+        # (np.kron with a block of ones, written as two repeats: same values, ~50x faster)
+        t += rng.uniform(-a, a, (size // s, size // s)).astype(np.float32).repeat(s, 0).repeat(s, 1)
     t = 0.25 * (t + np.roll(t, 1, 0) + np.roll(t, 1, 1) + np.roll(np.roll(t, 1, 0), 1, 1))
     return np.clip(t, 16, 240)
 
@@ -196,6 +196,99 @@ class Scene:
                 g = np.random.RandomState(noise_seed).standard_normal((h, w)).astype(np.float32)
                 img = img + noise_sigma * torch.from_numpy(g).to(dev)
         return img.round().clamp(0, 255).to(torch.uint8)
+
+
+# ---------------------------------------------------------------- fused GPU renderer
+class _SynthPlane(__import__("ctypes").Structure):
+    _fields_ = [("p0", __import__("ctypes").c_float * 3), ("u", __import__("ctypes").c_float * 3),
+                ("v", __import__("ctypes").c_float * 3), ("hu", __import__("ctypes").c_float),
+                ("hv", __import__("ctypes").c_float), ("off_u", __import__("ctypes").c_float),
+                ("off_v", __import__("ctypes").c_float)]
+
+
+class _SynthParams(__import__("ctypes").Structure):
+    _C = __import__("ctypes")
+    _fields_ = [("planes", _SynthPlane * 16), ("n_planes", _C.c_int), ("tex_size", _C.c_int),
+                ("tpm", _C.c_float), ("fx", _C.c_float), ("fy", _C.c_float), ("cx", _C.c_float),
+                ("cy", _C.c_float), ("w", _C.c_int), ("h", _C.c_int), ("noise_sigma", _C.c_float),
+                ("seed", _C.c_uint32)]
+
+
+_SYNTH_LIB = None
+
+
+def _synth_lib():
+    """csrc/libsvo_synth.so (synth_render.hip): one kernel per batch of frames instead of ~450
+    elementwise torch launches. Input generation only."""
+    global _SYNTH_LIB
+    if _SYNTH_LIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc", "libsvo_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+        _SYNTH_LIB = C.CDLL(path)
+    return _SYNTH_LIB
+
+
+def render_frames_gpu(scene, cfg, poses, right=False, noise_sigma=1.0, noise_seeds=None, out=None):
+    """uint8 [K, height, width] CUDA tensor: `scene` seen from `poses` [K, 6] (the library's left
+    camera, or the right one), rendered by one launch of csrc/synth_render.hip."""
+    import ctypes as C
+    dev = scene.device
+    assert dev.type == "cuda", "render_frames_gpu needs a scene on the GPU"
+    w, h = cfg["width"], cfg["height"]
+    poses = np.asarray(poses, np.float64).reshape(-1, 6)
+    K = poses.shape[0]
+    Rn = np.stack([rodrigues(p[3:6]) for p in poses])
+    on = poses[:, 0:3].copy()
+    if right:
+        on = on + Rn @ np.array([-cfg["baseline"] / cfg["fx"], 0.0, 0.0])
+    host = np.concatenate([Rn.reshape(K, 9), on], 1).astype(np.float32)
+    if not hasattr(scene, "_tex_stack"):
+        scene._tex_stack = torch.stack([pl["tex"] for pl in scene.planes]).contiguous()
+        par = _SynthParams()                      # plane table: built once per scene (reads device tensors)
+        par.n_planes = len(scene.planes)
+        par.tex_size = scene.planes[0]["tex"].shape[0]
+        par.tpm = scene.tpm
+        for i, pl in enumerate(scene.planes):
+            sp = par.planes[i]
+            p0, u, v = (pl[k].cpu().numpy() for k in ("p0", "u", "v"))
+            for j in range(3):
+                sp.p0[j] = float(p0[j]); sp.u[j] = float(u[j]); sp.v[j] = float(v[j])
+            sp.hu, sp.hv = pl["hu"], pl["hv"]
+            sp.off_u, sp.off_v = pl["off"]
+        scene._synth_par = par
+    par = scene._synth_par
+    par.fx, par.fy, par.cx, par.cy = cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"]
+    par.w, par.h = w, h
+    par.noise_sigma = noise_sigma
+    par.seed = 1 if right else 0
+    d_poses = torch.from_numpy(host).to(dev)
+    if noise_seeds is None:
+        noise_seeds = np.arange(K)
+    d_seeds = torch.from_numpy(np.asarray(noise_seeds, np.int64).astype(np.uint32).view(np.int32).copy()).to(dev)
+    if out is None:
+        out = torch.empty((K, h, w), dtype=torch.uint8, device=dev)
+    rc = _synth_lib().svo_synth_render(C.byref(par), C.c_void_p(scene._tex_stack.data_ptr()),
+                                       C.c_void_p(d_poses.data_ptr()), C.c_void_p(d_seeds.data_ptr()), K,
+                                       C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"svo_synth_render failed ({rc})")
+    return out
+
+
+def make_sequence_gpu(config="euroc", n_frames=10, seed=0, device="cuda", noise_sigma=1.0, motion_scale=1.0):
+    """make_sequence with the fused renderer (same scene and path, its own noise): returns
+    (cfg, lefts [n,H,W] uint8 CUDA tensor, rights, poses, timestamps)."""
+    cfg = dict(CONFIGS[config])
+    scene = Scene(seed, device)
+    poses = trajectory(n_frames, seed, motion_scale)
+    seeds = 7919 * (seed + 1) + 2 * np.arange(n_frames)
+    lefts = render_frames_gpu(scene, cfg, poses, False, noise_sigma, seeds)
+    rights = render_frames_gpu(scene, cfg, poses, True, noise_sigma, seeds + 1)
+    return cfg, lefts, rights, poses, np.arange(n_frames, dtype=np.float32) / 20.0
 
 
 def make_sequence(config="euroc", n_frames=10, seed=0, device="cpu", noise_sigma=1.0,

@@ -71,6 +71,22 @@ def test_sequence_sharding_is_a_partition():
     assert sorted(ids) == list(range(12))
 
 
+def test_longest_first_assignment_of_c4_sequences():
+    """C4: six sequences of unequal length on N ranks, longest first, every sequence
+    on exactly one rank; with eight ranks six stay busy, with two the loads differ by < 10 %."""
+    lengths = [2912, 1710, 2149, 2280, 2348, 1922]          # the EuRoC V1_01..V2_03 image counts of SURVEY §8d
+    for n in (1, 2, 4, 8):
+        parts = multi_seq.assign_longest_first(lengths, n)
+        assert len(parts) == n and sorted(sum(parts, [])) == list(range(6))
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) >= max(lengths)
+        if n == 8:
+            assert sum(1 for p in parts if p) == 6
+        if n == 2:
+            assert (max(loads) - min(loads)) / sum(loads) < 0.1
+    assert multi_seq.assign_longest_first(lengths, 1)[0] == [0, 4, 3, 2, 5, 1]
+
+
 def test_synthetic_stereo_geometry():
     """`right` is displaced toward -x: a point at depth z shifts by +baseline/z columns."""
     cfg, L, R, poses, ts = synth.make_sequence("tiny", 1, 0, device="cpu", noise_sigma=0.0)
@@ -139,6 +155,10 @@ def test_cpp_facade_builds_and_fails_loudly_without_gpu(tmp_path):
     assert gxx
     subprocess.check_call([gxx, "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "facade_smoke.cpp"),
                            "-o", exe, "-L" + csrc, "-lsvo_hip", "-Wl,-rpath," + csrc,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    # the stage classes (PoseEstimator, PoseRefiner, OpticalFlow, DepthFilter) build with g++ alone too
+    subprocess.check_call([gxx, "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "facade_stages.cpp"),
+                           "-o", str(tmp_path / "facade_stages"), "-L" + csrc, "-lsvo_hip", "-Wl,-rpath," + csrc,
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     import torch

@@ -278,3 +278,33 @@ def test_golden_vectors_real_pair():
     assert np.array_equal(dk, g["det_kps"]) and np.array_equal(dt, g["det_type"])
     # the real pair is a plausible stereo pair: most disparities are positive and finite
     assert (g["disp_31"] > 0.5).mean() > 0.8
+    # alignment of the pair against itself: the right image is the left camera moved by the baseline
+    cfg = dict(synth.CONFIGS["econ"])
+    cam = util.oracle_camera(cfg)
+    slam = O.Slam(cam)
+    slam.new_image(left, right, 0.0)
+    k2, k3, info = slam.keypoints()
+    assert np.array_equal(k2, g["kf0_kps2d"]) and np.array_equal(k3, g["kf0_kps3d"])
+    nl = cfg["max_pyramid_levels"]
+    pose, cost, tr = O.sparse_align(O.build_pyramid(left, nl), O.build_pyramid(right, nl), k2, k3,
+                                    util.flags_of(info), cam, np.zeros(6, np.float32))
+    assert np.array_equal(pose, g["sia_pose"]) and np.float32(cost) == g["sia_cost"]
+    assert [[t["n_gradient"], t["n_cost"], t["n_accepted"], t["exit_small"]] for t in tr] == g["sia_trace"].tolist()
+    assert abs(pose[0] + cfg["baseline"] / cfg["fx"]) < 0.01 and np.max(np.abs(pose[3:])) < 5e-3
+    m2, mfl = O.refine_merge(g["rp_proj0"], util.flags_of(info), g["rp_tracked"], g["rp_err"])
+    rpose, rcost, rtr = O.reproj_gn(m2, k3, mfl, cam, g["rp_start"])
+    assert np.array_equal(m2, g["rp_merged"]) and np.array_equal(rpose, g["rp_pose"])
+    assert [rtr["n_gradient"], rtr["n_cost"], rtr["n_accepted"], rtr["exit_small"]] == g["rp_trace"].tolist()
+
+
+def test_golden_sequence():
+    """The stored 5-frame sequence: the oracle tracker reproduces its committed poses, keypoints and
+    GN traces (regression of the restatement itself; the GPU twin is tests/test_golden_gpu.py)."""
+    s = np.load(os.path.join(util.GOLDEN, "golden_sequence.npz"))
+    slam = O.Slam(util.oracle_camera(dict(synth.CONFIGS["tiny"])))
+    for k in range(len(s["ts"])):
+        assert slam.new_image(s["left"][k], s["right"][k], float(s["ts"][k])) == int(s[f"f{k}_kf"])
+        k2, k3, info = slam.keypoints()
+        assert np.array_equal(slam.pose(), s[f"f{k}_pose"])
+        assert np.array_equal(k2, s[f"f{k}_kps2d"]) and np.array_equal(k3, s[f"f{k}_kps3d"])
+        assert np.array_equal(info, s[f"f{k}_info"])

@@ -79,3 +79,136 @@ def test_replay_synthetic_sequence(tmp_path):
     assert np.all(np.diff(rows[:, 0]) > 0)                   # cumulative algorithm time
     gt = synth.trajectory(10, 0)
     assert np.max(np.abs(rows[:, 1:4] - gt[:, :3])) < 0.06   # same envelope as the oracle test
+
+
+RECT_YAML = """%YAML:1.0
+Camera1.fx: 200.0
+Camera1.fy: 200.0
+Camera1.cx: 160.0
+Camera1.cy: 120.0
+Camera.baseline: 20.0
+Camera.grid_width: 40
+Camera.grid_height: 40
+Camera.search_x: 30
+Camera.search_y: 4
+Camera.window_size_pose_estimator: 4
+Camera.window_size_opt_flow: 21
+Camera.window_size_depth_calculator: 21
+Camera.max_pyramid_levels: 4
+Camera.min_pyramid_level_pose_estimation: 1
+LEFT.height: 240
+LEFT.width: 320
+RIGHT.height: 240
+RIGHT.width: 320
+{mats}
+"""
+
+
+def _mat(key, rows, cols, data):
+    return (f"{key}: !!opencv-matrix\n   rows: {rows}\n   cols: {cols}\n   dt: d\n   data: [" +
+            ", ".join(repr(float(v)) for v in data) + "]\n")
+
+
+def _write_euroc(tmp_path, k_shift=0.0):
+    """A three-frame EuRoC-layout dataset (mav0/cam0, cam1 + data.csv) of the synthetic tiny scene and
+    a settings file whose rectification is the identity (optionally: principal point moved by k_shift)."""
+    from PIL import Image
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", 3, 0, device="cpu")
+    mav = tmp_path / "mav0"
+    for cam in ("cam0", "cam1"):
+        (mav / cam / "data").mkdir(parents=True)
+    lines = ["#timestamp [ns],filename"]
+    for k in range(3):
+        stamp = 1403636579763555584 + k * 50000000
+        # cam0 is the physically left camera = the library's `right`; cam1 the library's `left`
+        Image.fromarray(R[k].numpy()).save(str(mav / "cam0" / "data" / f"{stamp}.png"))
+        Image.fromarray(L[k].numpy()).save(str(mav / "cam1" / "data" / f"{stamp}.png"))
+        lines.append(f"{stamp},{stamp}.png")
+    (mav / "cam0" / "data.csv").write_text("\r\n".join(lines) + "\r\n")
+    K = [200.0, 0, 160.0 + k_shift, 0, 200.0, 120.0, 0, 0, 1]
+    P = [200.0, 0, 160.0, 0, 0, 200.0, 120.0, 0, 0, 0, 1, 0]
+    eye = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    mats = ""
+    for side in ("LEFT", "RIGHT"):
+        mats += _mat(f"{side}.K", 3, 3, K) + _mat(f"{side}.D", 1, 5, [0] * 5) + _mat(f"{side}.R", 3, 3, eye) + \
+            _mat(f"{side}.P", 3, 4, P)
+    y = tmp_path / "cam.yaml"
+    y.write_text(RECT_YAML.format(mats=mats))
+    return str(mav) + "/", str(y), L, R
+
+
+def test_euroc_input_conventions(tmp_path):
+    """src/app/euroc_input.cpp:69-70,100-110: left <- cam1, right <- cam0, seconds since the first frame;
+    rectification maps from LEFT.* / RIGHT.* (identity here: images unchanged)."""
+    mav, y, L, R = _write_euroc(tmp_path)
+    src = replay.EurocInput(mav, y)
+    assert len(src) == 3
+    for k in range(3):
+        left, right, t = src.read(k)
+        assert np.array_equal(left, L[k].numpy()) and np.array_equal(right, R[k].numpy())
+        assert t == pytest.approx(0.05 * k, abs=1e-6)
+    s = replay.read_settings(y)
+    assert s["fx"] == 200.0 and s["search_x"] == 30
+
+
+def test_rectification_maps():
+    """cv::initUndistortRectifyMap: identity for K = P, R = I, D = 0; a principal point moved by 3 px
+    shifts the source position by 3 px; remap with a half-pixel shift averages neighbours."""
+    K = np.array([[200.0, 0, 160], [0, 200.0, 120], [0, 0, 1]])
+    P = np.hstack([K, np.zeros((3, 1))])
+    mx, my = replay.undistort_rectify_map(K, np.zeros(5), np.eye(3), P, (320, 240))
+    u, v = np.meshgrid(np.arange(320, dtype=np.float32), np.arange(240, dtype=np.float32))
+    assert np.allclose(mx, u, atol=1e-4) and np.allclose(my, v, atol=1e-4)
+    K2 = K.copy(); K2[0, 2] += 3
+    mx2, _ = replay.undistort_rectify_map(K2, np.zeros(5), np.eye(3), P, (320, 240))
+    assert np.allclose(mx2, u + 3, atol=1e-4)
+    img = (np.arange(240)[:, None] * 0 + np.arange(320)[None, :]).astype(np.uint8)
+    out = replay.remap_linear(img, u + 0.5, v)
+    assert np.array_equal(out[:, :250], np.rint(img[:, :250] + 0.5).astype(np.uint8))
+    # barrel distortion pulls the corners inwards
+    mx3, my3 = replay.undistort_rectify_map(K, np.array([-0.28, 0.07, 0, 0, 0]), np.eye(3), P, (320, 240))
+    assert mx3[0, 0] > 0 and my3[0, 0] > 0 and abs(mx3[120, 160] - 160) < 1e-3
+
+
+def test_side_by_side_input(tmp_path):
+    """src/app/video_input.cpp:35-36: `right` is the left half of the frame, `left` the right half."""
+    from PIL import Image
+    frame = np.zeros((40, 120), np.uint8)
+    frame[:, :60] = 10
+    frame[:, 60:] = 200
+    Image.fromarray(frame).save(str(tmp_path / "000000.png"))
+    src = replay.SideBySideInput(str(tmp_path / "%06d.png"), 1, fps=25.0)
+    left, right, t = src.read(0)
+    assert left.shape == (40, 60) and np.all(left == 200) and np.all(right == 10) and t == pytest.approx(0.04)
+
+
+def test_time_trace_uses_the_reference_stage_names():
+    class St:
+        stage_ms = [0.1, 0.01, 0.2, 0.3, 0.05, 0.07, 0.02, 0.4]
+        is_keyframe = 1
+    lines = replay.time_trace_lines(St)
+    names = [l.split(" took: ")[0] for l in lines]
+    assert names == ["Create pyramid", "estimator", "REFINEMENT: Optical flow", "pose refinement",
+                     "Filter update", "Create new keyframe", "Stereo SLAM"]
+    assert lines[3] == "pose refinement took: 0.3500ms"
+    St.is_keyframe = 0
+    assert "Create new keyframe" not in "".join(replay.time_trace_lines(St))
+
+
+@pytest.mark.gpu
+def test_replay_euroc_layout_equals_the_oracle(tmp_path, monkeypatch):
+    """$SVO_DATA pointing at a EuRoC mav0/ directory: the harness reads it with the reference's
+    conventions and the CSV it writes is the oracle's trajectory (reference-order mode)."""
+    import oracle_py as O
+    import util
+    mav, y, L, R = _write_euroc(tmp_path)
+    monkeypatch.setenv("SVO_DATA", mav)
+    out = tmp_path / "traj.csv"
+    replay.main(["--settings", y, "--frames", "3", "--exact", "-t", str(out)])
+    rows = np.loadtxt(str(out), delimiter=",")
+    cfg = dict(synth.CONFIGS["tiny"])
+    ref = O.Slam(util.oracle_camera(cfg))
+    for k in range(3):
+        ref.new_image(L[k].numpy(), R[k].numpy(), float(np.float32(0.05 * k)))
+        exp = np.concatenate([ref.pose()[:3], replay.csv_angles(ref.pose())])
+        assert np.allclose(rows[k, 1:], exp, atol=1e-6), k

@@ -22,11 +22,14 @@ def _compare_frame(tag, gpu_frame, ok2, ok3, oinfo, pose_ref, tol=1e-4):
     for f in INT_FIELDS:                                   # feature index lists: bit exact
         assert np.array_equal(gpu_frame.info[f], oinfo[f]), f"{tag}: info.{f}"
     assert np.array_equal(gpu_frame.info["score"], oinfo["score"]), f"{tag}: score"
+    if tol == 0.0:                                           # reference-order mode: the oracle's floats
+        assert np.array_equal(gpu_frame.pose, pose_ref), (tag, gpu_frame.pose, pose_ref)
+        assert np.array_equal(gpu_frame.kps2d, ok2) and np.array_equal(gpu_frame.kps3d, ok3), tag
+        return
     assert np.max(np.abs(gpu_frame.pose - pose_ref)) < tol, (tag, gpu_frame.pose, pose_ref)
     if len(ok2):
-        loose = tol > 1e-4                                   # stress sequence: positions follow the pose
-        assert np.max(np.abs(gpu_frame.kps2d - ok2)) < (0.3 if loose else 5e-2), f"{tag}: kps2d"
-        assert np.max(np.abs(gpu_frame.kps3d - ok3)) < (2e-2 if loose else 5e-3), f"{tag}: kps3d"
+        assert np.max(np.abs(gpu_frame.kps2d - ok2)) < 5e-2, f"{tag}: kps2d"
+        assert np.max(np.abs(gpu_frame.kps3d - ok3)) < 5e-3, f"{tag}: kps3d"
 
 
 def _same_trace(a, b, cfg):
@@ -41,11 +44,12 @@ def _same_trace(a, b, cfg):
 
 def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False, tol=None,
          render_device="cpu"):
-    """Both trackers frame by frame. exact (reference-order mode): every GN trace must equal the
-    oracle's and the pose bound is 1e-5; default mode: 1e-4. Returns the fraction of
-    tracked frames whose GN traces equal the oracle's as the third value."""
+    """Both trackers frame by frame. exact (the default, reference-order mode): every GN trace must
+    equal the oracle's and the pose is the oracle's bit for bit; exact=False (svo_ctx_set_fast_solver):
+    pose within 1e-4. Returns the fraction of tracked frames whose GN traces equal the
+    oracle's as the third value."""
     if tol is None:
-        tol = 1e-5 if exact else 1e-4
+        tol = 0.0 if exact else 1e-4
     cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device=render_device,
                                                motion_scale=motion_scale)
     L = [x.cpu() for x in L]
@@ -71,8 +75,7 @@ def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False,
         if k > 0:
             eq = _same_trace(st, ref.stats(), cfg)
             same += eq
-            # (1920x1080 runs the alignment from the HBM workspace, sia_big.hip: tree-order sums)
-            if exact and config != "hd":
+            if exact:
                 assert eq, f"{config}/{seed} frame {k}: GN trace differs from the oracle's"
     assert gpu.num_keyframes() == ref.num_keyframes() == n_kf
     for kid in range(n_kf):
@@ -136,21 +139,19 @@ def test_sequence_with_keyframe_creation():
     assert ref.num_keyframes() >= 2
 
 
-@pytest.mark.parametrize("exact", [False, True])
-def test_long_sequence_with_keyframes_at_full_size(exact):
+def test_long_sequence_with_keyframes_at_full_size():
     """Stress case: 60 frames of the C2 configuration at 3x the motion, several keyframes inside the
-    sequence. Feature index lists, flags and counters bit-exact on every frame, pose within the
-    stated 1e-4 in both modes; in reference-order mode every GN trace equals the oracle's."""
-    gpu, ref, same = _run("euroc", 60, 5, motion_scale=3.0, exact=exact, render_device="cuda")
-    assert ref.num_keyframes() >= 3
-    assert np.max(np.abs(gpu.get_frame().pose - ref.pose())) < (1e-5 if exact else 1e-4)
-    print(f"stress sequence, exact={exact}: {same:.3f} of the frames with the oracle's GN trace")
+    sequence. Default (reference-order) mode: feature index lists, flags, counters, poses and points
+    equal the oracle's on every frame, every GN trace too."""
+    gpu, ref, same = _run("euroc", 60, 5, motion_scale=3.0, exact=True, render_device="cuda")
+    assert ref.num_keyframes() >= 3 and same == 1.0
 
 
 def test_drift_over_300_frames():
     """trajectory drift against the restatement over 300 frames of the C2
-    configuration <= 1 mm / 0.01 deg, identical accept / reject trace on >= 99 % of the frames
-    (default mode; reference-order mode: on every frame, asserted inside _run)."""
+    configuration <= 1 mm / 0.01 deg, identical accept / reject trace on >= 99 % of the frames.
+    Default mode: no drift at all and every trace identical (asserted frame by frame in _run).
+    Fast-solver mode: the drift bound holds; its traces are its own (reported, not asserted)."""
     n = 300
     for exact in (True, False):
         gpu, ref, same = _run("euroc", n, 7, exact=exact, render_device="cuda")
@@ -159,7 +160,8 @@ def test_drift_over_300_frames():
         print(f"300 frames, exact={exact}: drift {drift_t * 1e3:.4f} mm / {np.degrees(drift_r):.5f} deg, "
               f"{same:.4f} of the frames with the oracle's GN trace, {ref.num_keyframes()} keyframes")
         assert drift_t <= 1e-3 and drift_r <= np.radians(0.01)
-        assert same >= 0.99
+        if exact:
+            assert same == 1.0 and drift_t == 0.0 and drift_r == 0.0
         gpu.close()
 
 
@@ -232,3 +234,79 @@ def test_update_pose_matches_oracle():
         a = gpu.update_pose(pose, speed, pv, sv, dt)
         b = ref.update_pose(pose, speed, pv, sv, dt)
         assert np.array_equal(a, b)
+
+
+def test_sequences_of_unequal_length_share_a_ctx():
+    """C4 mechanics: sequences of different lengths in ONE ctx. A sequence whose frames ran out sits
+    the remaining steps out (NULL image pointers); every sequence ends exactly like a ctx of its own."""
+    from stereo_svo_slam_amd import multi_seq
+    lengths = [7, 3, 5, 1]
+    seqs = [synth.make_sequence("tiny", n, 10 + s, device="cpu") for s, n in enumerate(lengths)]
+    cfg = seqs[0][0]
+    batch = StereoSlamBatch(cfg, cfg["width"], cfg["height"], len(lengths))
+    done = multi_seq.play_unequal(batch, lambda s, k: (seqs[s][1][k].numpy(), seqs[s][2][k].numpy()), lengths)
+    assert done == sum(lengths) and batch.totals().frames == sum(lengths)
+    for s, n in enumerate(lengths):
+        one = StereoSlam(cfg)
+        for k in range(n):
+            one.new_image(seqs[s][1][k].numpy(), seqs[s][2][k].numpy(), k / 20.0)
+        a, b = batch.get_frame(s), one.get_frame()
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.kps2d, b.kps2d)
+        assert np.array_equal(a.info, b.info)
+        assert batch.get_trajectory(s).shape == (n, 6)
+        one.close()
+    batch.close()
+
+
+TWO_RANK_WORKER = r"""
+import json, os, sys
+sys.path[:0] = [os.path.join(ROOT, "stereo-svo-slam_amd")]
+import numpy as np, torch
+from stereo_svo_slam_amd import multi_seq, synth
+from stereo_svo_slam_amd.stereo_slam import StereoSlamBatch
+rank, local_rank, world = multi_seq.init_distributed("gloo")
+device = torch.device("cuda", 0)                    # both ranks share the one GPU of the box
+lengths = [6, 4, 5, 3]
+mine = multi_seq.assign_longest_first(lengths, world)[rank]
+seqs = {s: synth.make_sequence("tiny", lengths[s], 20 + s, device="cpu") for s in mine}
+cfg = dict(synth.CONFIGS["tiny"])
+slam = StereoSlamBatch(cfg, cfg["width"], cfg["height"], len(mine), 0)
+my_len = [lengths[s] for s in mine]
+multi_seq._barrier(world, None)
+frames = multi_seq.play_unequal(slam, lambda i, k: (seqs[mine[i]][1][k].numpy(), seqs[mine[i]][2][k].numpy()), my_len)
+local = [[mine[i], my_len[i]] + [float(v) for v in slam.pose(i)] for i in range(len(mine))]
+local += [[-1, 0] + [0.0] * 6] * (2 - len(local))    # fixed-size summaries: two rows per rank
+allsum = multi_seq.gather_summaries(local, world, None)
+if rank == 0:
+    print(json.dumps({"summaries": allsum.tolist()}))
+"""
+
+
+def test_two_ranks_share_the_gpu(tmp_path):
+    """The multi-rank path with the HIP ctx in it (the CPU twin in tests/test_host_cpu.py drives the
+    oracle): two gloo ranks on the one GPU of the box, sequences of unequal length assigned longest
+    first, one all_gather of the per-sequence summaries; every pose equals a single-process run."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {root!r}\n" + TWO_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    summ = np.array([r for r in res["summaries"] if r[0] >= 0])
+    lengths = [6, 4, 5, 3]
+    assert sorted(summ[:, 0].astype(int).tolist()) == [0, 1, 2, 3]
+    cfg = dict(synth.CONFIGS["tiny"])
+    for row in summ:
+        s = int(row[0])
+        assert int(row[1]) == lengths[s]
+        L = synth.make_sequence("tiny", lengths[s], 20 + s, device="cpu")
+        one = StereoSlam(cfg)
+        for k in range(lengths[s]):
+            one.new_image(L[1][k].numpy(), L[2][k].numpy(), k / 20.0)
+        assert np.array_equal(np.float32(row[2:]), one.get_frame().pose)
+        one.close()

@@ -9,7 +9,7 @@ TAG=$1; shift
 FLAGS="$@"
 [ "$TAG" = stamps ] && FLAGS="-DSVO_SIA_STAMPS $FLAGS"
 mkdir -p $ROOT/build_ab/$TAG
-for f in svo_capi svo_ctx pyramid sia sia_big klt reproj depth keyframe; do
+for f in svo_capi svo_ctx pyramid sia klt reproj depth keyframe; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 $FLAGS -c $CSRC/$f.hip -o $ROOT/build_ab/$TAG/$f.o &
 done
 wait

@@ -14,7 +14,7 @@ from stereo_svo_slam_amd import synth
 from stereo_svo_slam_amd.stereo_slam import StereoSlam
 
 config, n_frames, seed, ms = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
-exact = "exact" in sys.argv[5:]
+exact = "fast" not in sys.argv[5:]
 show_all = "all" in sys.argv[5:]
 cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device="cuda" if torch.cuda.is_available() else "cpu",
                                            motion_scale=ms)

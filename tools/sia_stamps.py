@@ -11,8 +11,8 @@ import numpy as np, torch
 import oracle_py as O
 from stereo_svo_slam_amd import hip_lib
 import util
-config = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("exact",) else "euroc"
-exact = "exact" in sys.argv[1:]
+config = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("fast",) else "euroc"
+exact = "fast" not in sys.argv[1:]
 sc = util.scenario(config, 3, 0, 1)
 cfg = sc["cfg"]; nl = cfg["max_pyramid_levels"]
 prev, cur = O.build_pyramid(sc["L"][0], nl), O.build_pyramid(sc["L"][1], nl)
