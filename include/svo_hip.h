@@ -132,7 +132,11 @@ int svo_depth_filter_update(svo_handle *h, const svo_kp2d *kps2d, svo_kp3d *kps3
  * depth_calculator.cpp:135, are per sequence here). */
 typedef struct svo_ctx svo_ctx;
 
-enum { SVO_MEM_HOST = 0, SVO_MEM_DEVICE = 1 };
+/* SVO_MEM_DEVICE_BORROW: device images that the ctx uses IN PLACE as level 0 of its pyramids and
+ * as the right image — no copy, like the reference, whose level 0 is a shallow alias of the caller's
+ * cv::Mat (src/lib/stereo_slam.cpp:115). The caller keeps every image valid and unchanged while a
+ * frame or keyframe of the ctx refers to it (the safe choice: until svo_ctx_destroy). */
+enum { SVO_MEM_HOST = 0, SVO_MEM_DEVICE = 1, SVO_MEM_DEVICE_BORROW = 2 };
 
 /* StereoSlam::StereoSlam(const CameraSettings&)         src/lib/stereo_slam.cpp:29-41 */
 int svo_ctx_create(const svo_camera_settings *cam, int width, int height, int n_sequences,

@@ -165,6 +165,7 @@ __device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, con
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs* __restrict__ args, int cap) {
     constexpr int T = 64 * WAVES;
+    __builtin_amdgcn_s_setprio(3);     // latency-bound: win the issue arbitration against co-resident window kernels
     const ReprojArgs& a = args[blockIdx.x];
     const int n = min(*G(a.n_ptr), cap);
     const int tid = threadIdx.x;

@@ -355,10 +355,26 @@ struct Sia {
                 mat33f_vec(pm.Ri, X, X);
                 pose_jacobian(fx, fy, X[0], X[1], X[2], J);
             }
-            // residuals: the same walk over the patch as above, from the projection
+            // residuals: the same walk over the patch as above, from the projection. The 16 patch sums
+            // read a 6x6 block of the current image: it is loaded up front (36 independent reads,
+            // clamped to the image) and every patch sum whose taps start where the walk says they
+            // should — all of them, unless a float increment rounds across an integer — takes its 3x3
+            // taps from the block; the others read the image directly.
             float d[16];
             {
-                float kx = kpf_ld(KF_QX, i) - 2.f, ky = kpf_ld(KF_QY, i) - 2.f;
+                const float kx0 = kpf_ld(KF_QX, i) - 2.f, ky0 = kpf_ld(KF_QY, i) - 2.f;
+                const int bx = (int)fminf(fmaxf(floorf(kx0 - 0.5f), -8.f), 65536.f);
+                const int by = (int)fminf(fmaxf(floorf(ky0 - 0.5f), -8.f), 65536.f);
+                float blk[6][6];
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        const int ro = min(max(by + r, 0), cur.h - 1) * cur.stride;
+#pragma unroll
+                        for (int c = 0; c < 6; c++) blk[r][c] = cur.at(ro + min(max(bx + c, 0), cur.w - 1));
+                    }
+                }
+                float kx = kx0, ky = ky0;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -370,8 +386,22 @@ struct Sia {
                             // (kx - 1.0) < 0 || (ky - 1.0) < 0 || (kx + 2.0) > cols || (ky + 2.0) > rows of :449-454:
                             // the double sums are exact, so these float compares decide the same way
                             if (psr == psr &&                   // reference pixel inside (:449-451)
-                                !(kx < 1.f || ky < 1.f || kx > wlim || ky > hlim))
-                                dd = patch_sum_lds(cur, kx, ky) - psr;
+                                !(kx < 1.f || ky < 1.f || kx > wlim || ky > hlim)) {
+                                // get_patch_sum (:82-112) at (kx, ky)
+                                const float sx = kx - 0.5f, sy = ky - 0.5f;
+                                const int ipx = (int)floorf(sx), ipy = (int)floorf(sy);
+                                if (ipx == bx + c && ipy == by + r) {
+                                    const float x2 = sx - (float)ipx, y2 = sy - (float)ipy;
+                                    const float x1 = 1.0f - x2, y1 = 1.0f - y2;
+                                    const float intensity =
+                                        x1 * y1 * blk[r][c] + y1 * blk[r][c + 1] + x2 * y1 * blk[r][c + 2] +
+                                        x1 * blk[r + 1][c] + blk[r + 1][c + 1] + x2 * blk[r + 1][c + 2] +
+                                        x1 * y2 * blk[r + 2][c] + y2 * blk[r + 2][c + 1] + x2 * y2 * blk[r + 2][c + 2];
+                                    dd = intensity - psr;
+                                } else {
+                                    dd = patch_sum_lds(cur, kx, ky) - psr;
+                                }
+                            }
                         }
                         d[px] = dd;
                         kx += 1.f;
@@ -646,6 +676,9 @@ struct Sia {
 
 template <int WAVES, bool BIG>
 __global__ __launch_bounds__(64 * WAVES) void sia_gn_kernel(const SiaArgs* __restrict__ args, int img_bytes, int cap) {
+    // One or two waves per sequence, a long serial chain: when the window kernels of another
+    // sequence group share the SIMD, this wave should win the issue arbitration (it needs few slots)
+    __builtin_amdgcn_s_setprio(3);
     const SiaArgs& a = args[blockIdx.x];
     const int n = min(*G(a.n_ptr), cap);
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];

@@ -198,7 +198,7 @@ extern "C" int svo_build_pyramid(svo_handle* h, int n_levels, svo_image* levels)
     PyrArgs* d;
     int rc = stage(h, pa, &d);
     if (rc) return rc;
-    if (n_levels > 1) launch_pyr_halfsample(d, 1, levels[0].width, levels[0].height, false, h->stream);
+    if (n_levels > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -217,13 +217,14 @@ extern "C" int svo_build_lk_pyramid(svo_handle* h, int max_levels, int win, svo_
     }
     PyrArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.n_levels = n;
-    for (int l = 0; l < n; l++) pa.level[l] = make_view(levels[l]);
+    pa.n_levels = 1;
+    pa.level[0] = make_view(levels[0]);
+    pa.n_lk = n;
+    for (int l = 0; l < n; l++) pa.lk[l] = make_view(levels[l]);
     PyrArgs* d;
     int rc = stage(h, pa, &d);
     if (rc) return rc;
-    for (int l = 0; l + 1 < n; l++)
-        launch_pyr_down(d, 1, l, levels[l + 1].width, levels[l + 1].height, h->stream);
+    if (n > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, h->stream);
     HIP_TRY(hipGetLastError());
     if (n_out) *n_out = n;
     return SVO_OK;

@@ -152,6 +152,8 @@ struct ImageSet {
     ImgView left[SVO_MAX_PYRAMID_LEVELS];
     ImgView right;
     ImgView lk[SVO_LK_LEVELS];
+    ImgView own_left0, own_right;     // the set's own level-0 storage (left[0] / right alias the caller's
+                                      // images instead with SVO_MEM_DEVICE_BORROW)
     int refs = 0;
 };
 
@@ -355,6 +357,8 @@ int new_image_set(svo_group* c, ImageSet** out) {
     for (int l = 0; l < c->cam.max_pyramid_levels; l++) s->left[l].data = s->base + offs_left[l];
     s->right.data = s->base + off_right;
     s->lk[0] = s->left[0];
+    s->own_left0 = s->left[0];
+    s->own_right = s->right;
     for (int l = 1; l < c->n_lk; l++) s->lk[l].data = s->base + offs_lk[l];
     c->set_bytes = off;
     *out = s;
@@ -539,7 +543,6 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     size_t off = 0;
     auto reserve = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
     c->off_hs = reserve(sizeof(PyrArgs) * B);
-    c->off_lk = reserve(sizeof(PyrArgs) * B);
     c->off_compact = reserve(sizeof(CompactArgs) * B);
     c->off_sia = reserve(sizeof(SiaArgs) * B);
     c->off_klt = reserve(sizeof(KltArgs) * B);
@@ -745,7 +748,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     SVO_MARK(0);
 
     // ---- images in, pyramids
-    if (mem != SVO_MEM_DEVICE) {
+    if (mem == SVO_MEM_HOST) {
         const size_t used = (size_t)(c->height - 1) * stride + c->width;      // bytes of one frame that are read
         const size_t fb = align_up((size_t)c->height * stride, 256);
         if (fb > c->stage_frame_bytes) {
@@ -785,18 +788,27 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         PyrArgs* hs = args_at<PyrArgs>(c, c->off_hs, j);
         std::memset(hs, 0, sizeof(*hs));
         hs->n_levels = c->cam.max_pyramid_levels;
+        if (mem == SVO_MEM_DEVICE_BORROW) {
+            // level 0 of both pyramids and the right image ARE the caller's images (like the
+            // reference's shallow cv::Mat alias, stereo_slam.cpp:115): nothing is copied
+            is->left[0] = ImgView{left[s], c->width, c->height, stride};
+            is->right = ImgView{right[s], c->width, c->height, stride};
+            hs->src_left = is->left[0];
+        } else {
+            // frames are ingested by the pyramid kernel itself (one launch for all sequences instead of
+            // 2 copies per sequence); host-resident ones come through the staging buffer filled above
+            is->left[0] = is->own_left0;
+            is->right = is->own_right;
+            const uint8_t* src_l = mem == SVO_MEM_DEVICE ? left[s] : c->d_stage_in + (size_t)s * c->stage_frame_bytes;
+            const uint8_t* src_r = mem == SVO_MEM_DEVICE ? right[s] : c->d_stage_in + (size_t)(c->B + s) * c->stage_frame_bytes;
+            hs->src_left = ImgView{src_l, c->width, c->height, stride};
+            hs->src_right = ImgView{src_r, c->width, c->height, stride};
+            hs->dst_right = is->right;
+        }
+        is->lk[0] = is->left[0];
         for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
-        // frames are ingested by the pyramid kernel itself (one launch for all sequences instead of
-        // 2 copies per sequence); host-resident ones come through the staging buffer filled above
-        const uint8_t* src_l = mem == SVO_MEM_DEVICE ? left[s] : c->d_stage_in + (size_t)s * c->stage_frame_bytes;
-        const uint8_t* src_r = mem == SVO_MEM_DEVICE ? right[s] : c->d_stage_in + (size_t)(c->B + s) * c->stage_frame_bytes;
-        hs->src_left = ImgView{src_l, c->width, c->height, stride};
-        hs->src_right = ImgView{src_r, c->width, c->height, stride};
-        hs->dst_right = is->right;
-        PyrArgs* lk = args_at<PyrArgs>(c, c->off_lk, j);
-        std::memset(lk, 0, sizeof(*lk));
-        lk->n_levels = c->n_lk;
-        for (int l = 0; l < c->n_lk; l++) lk->level[l] = is->lk[l];
+        hs->n_lk = c->n_lk;
+        for (int l = 0; l < c->n_lk; l++) hs->lk[l] = is->lk[l];
     }
 
     if (!first) {
@@ -861,14 +873,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     hlap(0);   // argument blocks
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, first ? c->args_bytes : c->frame_args_bytes,
                            hipMemcpyHostToDevice, c->stream));
-    launch_pyr_halfsample(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, true, c->stream);
-    {
-        int w = c->width, h = c->height;
-        for (int l = 0; l + 1 < c->n_lk; l++) {
-            w = (w + 1) / 2; h = (h + 1) / 2;
-            launch_pyr_down(dargs_at<PyrArgs>(c, c->off_lk), M, l, w, h, c->stream);
-        }
-    }
+    launch_pyr_fused(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, mem != SVO_MEM_DEVICE_BORROW, c->stream);
     std::vector<int> need(B, 0);
     if (first) {
         for (int s = 0; s < B; s++) {

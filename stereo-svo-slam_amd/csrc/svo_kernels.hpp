@@ -13,16 +13,18 @@ namespace svo {
 
 // ---------------------------------------------------------------- pyramids
 struct PyrArgs {
-    ImgView level[SVO_MAX_PYRAMID_LEVELS];  // [0] = input (or its resident copy), [1..] = outputs
+    ImgView level[SVO_MAX_PYRAMID_LEVELS];  // halfSample pyramid: [0] = input (or its resident copy), [1..] = outputs
     int n_levels;
+    ImgView lk[SVO_LK_LEVELS];              // Gaussian (LK) pyramid: [0] = level[0], [1..] = outputs
+    int n_lk;                               // LK levels to build (<= 1: none)
     // optional ingest of device-resident caller images (svo_new_images, SVO_MEM_DEVICE):
     // level[0] is then WRITTEN from src_left while the pyramid is built, and the
     // right image is copied by the blocks with blockIdx.z >= batch.
     ImgView src_left, src_right, dst_right;
 };
-void launch_pyr_halfsample(const PyrArgs* d_args, int batch, int w, int h, bool ingest, hipStream_t stream);
-void launch_pyr_down(const PyrArgs* d_args, int batch, int src_level, int dst_w, int dst_h,
-                     hipStream_t stream);
+// both pyramids of `batch` left images of w x h in one launch; right_blocks: extra workgroups copy
+// src_right -> dst_right (ingest of device-resident frames)
+void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, hipStream_t stream);
 
 // ------------------------------------------------- sparse image alignment
 struct SiaArgs {

@@ -125,10 +125,11 @@ class StereoSlamBatch:
         ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
         _check(lib().svo_new_images(self._ctx, ptrs_l, ptrs_r, stride, ts, 1 if on_dev else 0))
 
-    def pack_images(self, lefts, rights, time_stamps):
+    def pack_images(self, lefts, rights, time_stamps, borrow=False):
         """Pre-build the argument arrays of one step (keeps Python out of a timed loop); pass the
         result to new_images_packed / submit_packed. The frames are torch uint8 tensors, all on
-        the GPU (SVO_MEM_DEVICE) or all in host memory (SVO_MEM_HOST; pinned for full PCIe rate)."""
+        the GPU (SVO_MEM_DEVICE; with borrow=True SVO_MEM_DEVICE_BORROW: used in place, the caller
+        keeps them alive and unchanged) or all in host memory (SVO_MEM_HOST; pinned for full PCIe rate)."""
         ptrs_l = (C.c_void_p * self.n)()
         ptrs_r = (C.c_void_p * self.n)()
         some = next(x for x in lefts if x is not None)
@@ -142,7 +143,7 @@ class StereoSlamBatch:
                 assert tuple(arr.shape) == (self.height, self.width) and arr.stride(0) == stride
                 dst[s] = arr.data_ptr()
         ts = (C.c_float * self.n)(*[float(t) for t in time_stamps])
-        return ptrs_l, ptrs_r, stride, ts, (lefts, rights), 1 if on_dev else 0
+        return ptrs_l, ptrs_r, stride, ts, (lefts, rights), (2 if borrow else 1) if on_dev else 0
 
     def new_images_packed(self, packed):
         _check(lib().svo_new_images(self._ctx, packed[0], packed[1], packed[2], packed[3], packed[5]))

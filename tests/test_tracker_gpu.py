@@ -310,3 +310,25 @@ def test_two_ranks_share_the_gpu(tmp_path):
             one.new_image(L[1][k].numpy(), L[2][k].numpy(), k / 20.0)
         assert np.array_equal(np.float32(row[2:]), one.get_frame().pose)
         one.close()
+
+
+def test_borrowed_device_frames_equal_copied_ones():
+    """SVO_MEM_DEVICE_BORROW: level 0 of the pyramids and the right image alias the caller's device
+    images (the reference's own shallow cv::Mat alias); results equal the copying SVO_MEM_DEVICE
+    path, keyframes (which keep referring to old frames) included."""
+    import torch
+    n_frames = 14
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", n_frames, 1, device="cpu", motion_scale=4.0)
+    dl = [x.cuda() for x in L]
+    dr = [x.cuda() for x in R]
+    torch.cuda.synchronize()
+    a = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1)
+    b = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1)
+    for k in range(n_frames):
+        a.new_images_packed(a.pack_images([dl[k]], [dr[k]], [float(ts[k])]))
+        b.new_images_packed(b.pack_images([dl[k]], [dr[k]], [float(ts[k])], borrow=True))
+        fa, fb = a.get_frame(0), b.get_frame(0)
+        assert np.array_equal(fa.pose, fb.pose) and np.array_equal(fa.kps2d, fb.kps2d)
+        assert np.array_equal(fa.info, fb.info)
+    assert a.num_keyframes(0) == b.num_keyframes(0) >= 2
+    a.close(); b.close()
