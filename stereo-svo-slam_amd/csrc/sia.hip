@@ -79,20 +79,21 @@ __device__ inline float patch_sum_lds(const LevelImg<BIG>& im, float cx, float c
 // Dynamic LDS of one workgroup (byte offsets). cap = keypoint capacity (multiple of 64),
 // T = threads. Per keypoint: 9 floats (point, last projection, sum g g^T, active) and the
 // 64 per-pixel records, all struct-of-arrays with the keypoint index fastest (conflict free).
+constexpr int SIA_STG = 16;             // keypoints whose rows are staged at a time in reference-order mode
 enum { KF_PX = 0, KF_PY, KF_PZ, KF_QX, KF_QY, KF_GXX, KF_GXY, KF_GYY, KF_ACT, KF_COUNT };
 enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
 struct SiaLds {
     size_t img, tbuf, kpf, rec, sums, stage, total;
 };
-__host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact, bool big = false) {
+__host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact, int mode = 0) {
     SiaLds l;
     size_t off = 0;
-    l.img = off;   off += big ? 0 : ((size_t)img_bytes + 15) & ~(size_t)15;
-    l.tbuf = off;  off += (size_t)2 * cap * 4;
-    l.kpf = off;   off += big ? 0 : (size_t)KF_COUNT * cap * 4;
-    l.rec = off;   off += big ? 0 : (size_t)64 * cap * 4;
+    l.img = off;   off += mode == 2 ? 0 : ((size_t)img_bytes + 15) & ~(size_t)15;
+    l.tbuf = off;  off += T == 64 ? 0 : (size_t)2 * cap * 4;             // one wave sums by v_readlane
+    l.kpf = off;   off += mode == 2 ? 0 : (size_t)KF_COUNT * cap * 4;
+    l.rec = off;   off += mode == 2 ? 0 : (size_t)(mode == 1 ? 16 : 64) * cap * 4;
     l.sums = off;  off += 16 * 32 * 4;                                 // [WAVES <= 16][32]
-    l.stage = off; off += exact ? (size_t)7 * (64 * 20 + 4) * 4 : 0;  // 7 planes of one wave's rows (20 floats per keypoint)
+    l.stage = off; off += exact ? (size_t)7 * (SIA_STG * 20 + 4) * 4 : 0;   // 7 planes of SIA_STG keypoints' rows (20 floats each)
     l.total = off;
     return l;
 }
@@ -196,12 +197,19 @@ __global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict
 #define SIA_ADD(i, t1, t0)
 #endif
 
-// BIG: keypoint sets / level images that do not fit LDS (the 1920x1080 configuration: ~1700
-// keypoints, 480x270 finest level). The per-keypoint values then live in the HBM workspace
-// SiaArgs::kp_ws, the records are read where sia_prep_kernel wrote them and the image taps come
-// from L2; the arithmetic and its order are the same.
-template <int WAVES, bool BIG>
+// MODE — where the working set of a sequence lives (same arithmetic, same order in all three):
+//   0 (a few sequences, latency matters): level image, per-keypoint values and all records in LDS;
+//   1 (a batch of sequences): image, per-keypoint values and the cost records (i1) in LDS, the
+//     records only get_gradient needs (reference patch sums, image gradients, sum g g^T: 3/4 of
+//     the bytes) are read where sia_prep_kernel wrote them — ~45 KB of LDS per sequence instead
+//     of ~100 KB, so the workgroup finds room on a CU that another sequence group's window
+//     kernels are filling;
+//   2 (BIG: keypoint sets / level images that do not fit LDS, the 1920x1080 configuration with
+//     ~1700 keypoints and a 480x270 finest level): per-keypoint values in the HBM workspace
+//     SiaArgs::kp_ws, records and image taps from L2.
+template <int WAVES, int MODE>
 struct Sia {
+    static constexpr bool BIG = MODE == 2;
     static constexpr int T = 64 * WAVES;
 #ifdef SVO_SIA_STAMPS
     long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -229,30 +237,33 @@ struct Sia {
         else (LDSF(dyn + lay.kpf) + f * cap)[i] = v;
     }
     __device__ inline float rec_ld(int f, int px, int i) const {
-        if constexpr (BIG) return ((SVO_GP(const float))recs)[(size_t)(f * 16 + px) * a.rec_cap + i];
+        if (BIG || (MODE == 1 && f != REC_I1))
+            return ((SVO_GP(const float))recs)[(size_t)(f * 16 + px) * a.rec_cap + i];
         else return (LDSF(dyn + lay.rec) + (f * 16 + px) * cap)[i];
     }
     __device__ inline float g_ld(int k, int i) const {       // sum g g^T: Gxx, Gxy, Gyy
-        if constexpr (BIG) return ((SVO_GP(const float))recs)[(size_t)(64 + k) * a.rec_cap + i];
+        if constexpr (MODE != 0) return ((SVO_GP(const float))recs)[(size_t)(64 + k) * a.rec_cap + i];
         else return (LDSF(dyn + lay.kpf) + (KF_GXX + k) * cap)[i];
     }
 
     // ---- per-level records (sia_prep_kernel wrote them): HBM -> LDS, 16 B per lane and step
     __device__ void load_records(int slot) {
         const float* src = G(a.rec_ws) + (size_t)slot * SIA_REC_ROWS * a.rec_cap;
-        if constexpr (BIG) { recs = src; return; }
-        // cap is a multiple of T, so a lane keeps its float4 column and walks the 67 rows, 8 loads in flight
+        recs = src;
+        if constexpr (BIG) return;
+        constexpr int n_rows = MODE == 1 ? 16 : 67;          // MODE 1: only the cost records (field REC_I1 = rows 0..15)
+        // cap is a multiple of T, so a lane keeps its float4 column and walks the rows, 8 loads in flight
         const int c4 = cap >> 2;
         for (int col4 = threadIdx.x; col4 < c4; col4 += T) {
-            for (int r0 = 0; r0 < 67; r0 += 8) {
+            for (int r0 = 0; r0 < n_rows; r0 += 8) {
                 v4f v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    if (r0 + u < 67) v[u] = *reinterpret_cast<const v4f*>(src + (size_t)(r0 + u) * a.rec_cap + 4 * col4);
+                    if (r0 + u < n_rows) v[u] = *reinterpret_cast<const v4f*>(src + (size_t)(r0 + u) * a.rec_cap + 4 * col4);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int row = r0 + u;
-                    if (row < 67) {
+                    if (row < n_rows) {
                         SVO_LDS(float)* dst = row < 64 ? LDSF(dyn + lay.rec) + row * cap + 4 * col4
                                                        : LDSF(dyn + lay.kpf) + (KF_GXX + (row - 64)) * cap + 4 * col4;
                         *(SVO_LDS(v4f)*)dst = v[u];
@@ -341,8 +352,8 @@ struct Sia {
         float eacc = 0;
         const float wlim = (float)(cur.w - 2), hlim = (float)(cur.h - 2);
         constexpr int KS = 20;                       // floats per keypoint in a staging plane (16 + pad: no write conflicts)
-        constexpr int PS = 64 * KS + 4;              // plane stride: the 7 planes start on different banks
-        float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index px*64 + lane
+        constexpr int PS = SIA_STG * KS + 4;         // plane stride: the 7 planes start on different banks
+        float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index slot*KS + px
 
         for (int i0 = 0; i0 < cap; i0 += T) {
             const int i = i0 + tid;
@@ -431,11 +442,12 @@ struct Sia {
 #pragma unroll
                 for (int r = 0; r < 6; r++) acc[21 + r] -= J[r] * s0 + J[6 + r] * s1;
             } else {
-                // One wave at a time stages the rows of gradient_times_jacobians (:376-388) and the
-                // diffs of its 64 keypoints, pixel-major; wave 0 adds them in storage order.
-                for (int w = 0; w < WAVES; w++) {
-                    sia_sync<WAVES>();                      // the previous 64 keypoints have been consumed
-                    if (wave == w) {
+                // SIA_STG keypoints at a time stage the rows of gradient_times_jacobians (:376-388) and the
+                // diffs, keypoint-major; wave 0 adds them in storage order.
+                for (int sub = 0; sub < T / SIA_STG; sub++) {
+                    sia_sync<WAVES>();                      // the previous keypoints have been consumed
+                    if ((tid / SIA_STG) == sub) {
+                        const int slot = tid % SIA_STG;
 #pragma unroll
                         for (int p4 = 0; p4 < 4; p4++) {
                             float g0[4], g1[4];
@@ -454,16 +466,16 @@ struct Sia {
                                     sum += g1[e] * J[6 + q];
                                     row[e] = sum;
                                 }
-                                *(SVO_LDS(v4f)*)(LDSF(stage) + q * PS + lane * KS + p4 * 4) = row;
+                                *(SVO_LDS(v4f)*)(LDSF(stage) + q * PS + slot * KS + p4 * 4) = row;
                             }
                             // residual -= row * diff (:472-477) == residual += row * (-diff), exactly
-                            *(SVO_LDS(v4f)*)(LDSF(stage) + 6 * PS + lane * KS + p4 * 4) =
+                            *(SVO_LDS(v4f)*)(LDSF(stage) + 6 * PS + slot * KS + p4 * 4) =
                                 v4f{-d[p4 * 4], -d[p4 * 4 + 1], -d[p4 * 4 + 2], -d[p4 * 4 + 3]};
                         }
                     }
                     sia_sync<WAVES>();
                     if (wave == 0 && lane < 27) {
-                        const int m = min(64, n - (i0 + w * 64));   // keypoints of this chunk, in index order
+                        const int m = min(SIA_STG, n - (i0 + sub * SIA_STG));   // keypoints of this chunk, in index order
                         const SVO_LDS(float)* pa = LDSCF(stage) + ia * PS;
                         const SVO_LDS(float)* pb = LDSCF(stage) + ib * PS;
                         // hessian += row^T row (lanes 0..20), residual += row * (-diff) (lanes 21..26):
@@ -674,16 +686,22 @@ struct Sia {
     }
 };
 
-template <int WAVES, bool BIG>
-__global__ __launch_bounds__(64 * WAVES) void sia_gn_kernel(const SiaArgs* __restrict__ args, int img_bytes, int cap) {
+// (diagnostic builds: -DSVO_SIA_OCC=n caps the registers at 512/n per lane, tools/build_variants.sh)
+#ifdef SVO_SIA_OCC
+#define SIA_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_SIA_OCC)))
+#else
+#define SIA_OCC_ATTR
+#endif
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES) SIA_OCC_ATTR void sia_gn_kernel(const SiaArgs* __restrict__ args, int img_bytes, int cap) {
     // One or two waves per sequence, a long serial chain: when the window kernels of another
     // sequence group share the SIMD, this wave should win the issue arbitration (it needs few slots)
     __builtin_amdgcn_s_setprio(3);
     const SiaArgs& a = args[blockIdx.x];
     const int n = min(*G(a.n_ptr), cap);
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    const SiaLds lay = sia_lds_layout(img_bytes, cap, 64 * WAVES, a.exact_pinv != 0, BIG);
-    Sia<WAVES, BIG> s(a, n, cap, dyn, lay);
+    const SiaLds lay = sia_lds_layout(img_bytes, cap, 64 * WAVES, a.exact_pinv != 0, MODE);
+    Sia<WAVES, MODE> s(a, n, cap, dyn, lay);
     s.run();
 }
 
@@ -698,13 +716,13 @@ static int sia_img_bytes(const svo_camera_settings& cam, int width, int height) 
     return best;
 }
 
-template <int WAVES, bool BIG>
+template <int WAVES, int MODE>
 static void sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap, size_t lds, hipStream_t stream) {
     static std::atomic<bool> configured{false};
     if (!configured.exchange(true))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES, BIG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIA_LDS_BUDGET);
-    hipLaunchKernelGGL((sia_gn_kernel<WAVES, BIG>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
+    hipLaunchKernelGGL((sia_gn_kernel<WAVES, MODE>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
 }
 
 // Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints, one keypoint per
@@ -717,29 +735,33 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     const int n_lv = cam.max_pyramid_levels - cam.min_pyramid_level_pose_estimation;
     const int img = sia_img_bytes(cam, width, height);
     // many sequences: half as many waves (two passes each) — the wave-uniform work (SVD, Rodrigues,
-    // the ordered sums) is then not duplicated on a second SIMD that other kernels could use
+    // the ordered sums) is then not duplicated on a second SIMD that other kernels could use — and
+    // the gradient-only records stay in HBM (MODE 1) to keep the LDS footprint small
+    const bool batched = batch >= 32;
     int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
-    if (batch >= 32 && waves > 1 && waves < 8) waves /= 2;
+    if (batched && waves > 1 && waves < 8) waves /= 2;
+    int mode = batched ? 1 : 0;
     int T = 64 * waves;
     int cap = (nb + T - 1) / T * T;                   // every lane of every pass owns a slot
-    size_t lds = sia_lds_layout(img, cap, T, exact != 0).total;
-    const bool big = lds > SIA_LDS_BUDGET;
-    if (big) {
-        waves = 8; T = 512;
+    size_t lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
+    if (lds > SIA_LDS_BUDGET && mode == 0) {
+        mode = 1;
+        lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
+    }
+    if (lds > SIA_LDS_BUDGET) {
+        mode = 2; waves = 8; T = 512;
         cap = (nb + T - 1) / T * T;
-        lds = sia_lds_layout(img, cap, T, exact != 0, true).total;
+        lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
         if (lds > SIA_LDS_BUDGET) return false;
     }
     if (cap > rec_cap) return false;
     hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 255) / 256, n_lv, batch), dim3(256), 0, stream, d_args);
-    if (big) { sia_launch_shape<8, true>(d_args, batch, img, cap, lds, stream); return true; }
-    switch (waves) {
-        case 1: sia_launch_shape<1, false>(d_args, batch, img, cap, lds, stream); break;
-        case 2: sia_launch_shape<2, false>(d_args, batch, img, cap, lds, stream); break;
-        case 4: sia_launch_shape<4, false>(d_args, batch, img, cap, lds, stream); break;
-        default: sia_launch_shape<8, false>(d_args, batch, img, cap, lds, stream); break;
-    }
-    return true;
+#define SIA_CASE(W, M) if (waves == W && mode == M) { sia_launch_shape<W, M>(d_args, batch, img, cap, lds, stream); return true; }
+    SIA_CASE(1, 0) SIA_CASE(2, 0) SIA_CASE(4, 0) SIA_CASE(8, 0)
+    SIA_CASE(1, 1) SIA_CASE(2, 1) SIA_CASE(4, 1) SIA_CASE(8, 1)
+    SIA_CASE(8, 2)
+#undef SIA_CASE
+    return false;
 }
 
 size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap) {

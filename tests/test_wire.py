@@ -51,3 +51,31 @@ def test_messages_have_the_reference_layout():
     assert len(t) == 12 and np.allclose(t[6:], s.traj[1])               # raw angles, flat
     assert wire.handle("unknown", "get", s) is None
     assert " " not in wire.pose_message(s)                               # QJsonDocument::Compact
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_keyframes_message_of_a_real_tracker_carries_the_colours():
+    """keyframes_message on a real StereoSlam: every keyframe keypoint arrives with its colour and
+    its 3-D point (the keyframe keeps the full keypoint info, src/lib/keyframe_manager.cpp:27-29;
+    the backend sends info.color per keypoint, src/app/svo_slam_backend.cpp:51-55)."""
+    import oracle_py as O
+    import util
+    from stereo_svo_slam_amd import synth
+    from stereo_svo_slam_amd.stereo_slam import StereoSlam
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", 14, 1, device="cpu", motion_scale=4.0)
+    gpu = StereoSlam(cfg)
+    ref = O.Slam(util.oracle_camera(cfg))
+    for k in range(14):
+        gpu.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        ref.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+    kfs = json.loads(wire.keyframes_message(gpu))
+    assert len(kfs) == ref.num_keyframes() >= 2
+    for kid, kf in enumerate(kfs):
+        k2, k3, info, pose = ref.keyframe(kid)
+        assert [(c["r"], c["g"], c["b"]) for c in kf["colors"]] == [tuple(int(v) for v in c) for c in info["color"]]
+        assert any(c != {"r": 0, "g": 0, "b": 0} for c in kf["colors"])
+        assert np.allclose([[p["x"], p["y"], p["z"]] for p in kf["keypoints"]], k3, atol=0)
+    gpu.close()

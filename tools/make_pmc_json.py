@@ -1,0 +1,76 @@
+"""Condenses the rocprofv3 outputs of tools/profile_r02.sh into the files bench.py reads:
+pmc.json (per kernel: the roof that binds it and the fraction of it that is reached) and
+traffic.json (HBM bytes per launch: FETCH_SIZE corrected x2 as the guide prescribes for gfx950,
++ WRITE_SIZE). Usage: make_pmc_json.py <dir with sq.csv FETCH_SIZE.csv WRITE_SIZE.csv> <out dir>"""
+import collections
+import csv
+import json
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+N_SIMD = 256 * 4
+CLK = 2.4e9                      # max shader clock, MI355X_MICROARCH.md
+VALU_CYCLES = 2                  # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("svo::", "").split("<")[0]
+
+
+def collect(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+bench = json.loads(open(f"{out}/bench_under_rocprof.json").read().strip().splitlines()[-1])
+dur = {}
+for r in csv.DictReader(open(f"{out}/kernel_stats.csv")):
+    if "svo::" in r["Name"]:
+        dur[short(r["Name"])] = float(r["AverageNs"]) * 1e-9
+sq = collect(f"{src}/sq.csv")
+with open(f"{out}/pmc_sq.csv", "w") as f:
+    f.write("kernel,counter,mean_per_dispatch\n")
+    for k in sorted(sq):
+        for c in sorted(sq[k]):
+            f.write(f"{k},{c},{sq[k][c]:.1f}\n")
+kernels = {}
+for k, c in sq.items():
+    if k not in dur or "SQ_WAVE_CYCLES" not in c:
+        continue
+    wc = max(c["SQ_WAVE_CYCLES"], 1.0)
+    active, wait, issue_stall = c.get("SQ_ACTIVE_INST_ANY", 0) / wc, c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc
+    valu_rate = c.get("SQ_INSTS_VALU", 0) * VALU_CYCLES / (dur[k] * CLK * N_SIMD)
+    e = {"wave_cycles_issuing": active, "wave_cycles_waiting": wait, "wave_cycles_issue_stalled": issue_stall,
+         "valu_instructions_per_dispatch": c.get("SQ_INSTS_VALU", 0), "salu_instructions_per_dispatch": c.get("SQ_INSTS_SALU", 0),
+         "waves_per_dispatch": c.get("SQ_WAVES", 0), "avg_dispatch_s": dur[k]}
+    if valu_rate > 0.2:
+        e.update(bound="valu_issue", frac=valu_rate,
+                 note="wave64 VALU instructions x 2 cycles / (dispatch time x 2.4 GHz x 1024 SIMDs)")
+    elif wait > 0.6 and c.get("SQ_WAVES", 0) < 4096:
+        e.update(bound="latency", frac=active,
+                 note="one or two wavefronts per sequence run a serial Gauss-Newton chain: fraction of the "
+                      "wave's cycles in which it issues (the rest waits on LDS / memory / dependent math)")
+    else:
+        e.update(bound="memory_latency", frac=active,
+                 note="streaming kernel: fraction of wave cycles issuing; see hbm_frac for the bandwidth roof")
+    kernels[k] = e
+cfg = bench["config"]
+meta = {"config": bench["config"]["workload"].split(":")[0], "seqs": cfg["sequences_per_gpu"], "groups": cfg["sequence_groups"]}
+json.dump({**meta, "kernels": kernels,
+           "note": "rocprofv3 --pmc SQ_* pass of the default bench command (own run, kernel-include-regex svo); "
+                   "durations from the --kernel-trace --stats run of the same command"},
+          open(f"{out}/pmc.json", "w"), indent=1)
+fetch, write = collect(f"{src}/FETCH_SIZE.csv"), collect(f"{src}/WRITE_SIZE.csv")
+traffic = {}
+for k in set(fetch) | set(write):
+    fs = fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024          # rocprofv3 reports KiB
+    ws = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+    traffic[k] = {"fetch_raw": fs, "fetch_x2": 2 * fs, "write": ws, "total": 2 * fs + ws}
+json.dump({**meta, "bytes_per_launch": {k: v["total"] for k, v in traffic.items()}, "detail": traffic,
+           "note": "FETCH_SIZE x 2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section) + "
+                   "WRITE_SIZE, separate --pmc passes, mean per dispatch"},
+          open(f"{out}/traffic.json", "w"), indent=1)
+print(json.dumps({k: {"bound": v["bound"], "frac": round(v["frac"], 4)} for k, v in kernels.items()}, indent=1))
+print(json.dumps({k: round(v / 1e6, 2) for k, v in sorted(json.load(open(f"{out}/traffic.json"))["bytes_per_launch"].items())}))
