@@ -133,6 +133,7 @@ __device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, con
             const SVO_LDS(rp_v4f)* p1 = (const SVO_LDS(rp_v4f)*)sh.js[i1];
             const SVO_LDS(rp_v4f)* p2 = (const SVO_LDS(rp_v4f)*)sh.js[i2];
             const SVO_LDS(rp_v4f)* p3 = (const SVO_LDS(rp_v4f)*)sh.js[i3];
+#pragma unroll 4
             for (int j = 0; j < (m + 3) >> 2; j++) {
                 const rp_v4f x0 = p0[j], x1 = p1[j], x2 = p2[j], x3 = p3[j];
                 { float s = 0; s += x0.x * x2.x; s += x1.x * x3.x; acc += s; }

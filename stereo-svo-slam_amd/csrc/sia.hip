@@ -38,6 +38,7 @@
 #include "svo_kernels.hpp"
 #include <atomic>
 #include <algorithm>
+#include <cstdlib>
 
 namespace svo {
 
@@ -79,7 +80,10 @@ __device__ inline float patch_sum_lds(const LevelImg<BIG>& im, float cx, float c
 // Dynamic LDS of one workgroup (byte offsets). cap = keypoint capacity (multiple of 64),
 // T = threads. Per keypoint: 9 floats (point, last projection, sum g g^T, active) and the
 // 64 per-pixel records, all struct-of-arrays with the keypoint index fastest (conflict free).
-constexpr int SIA_STG = 16;             // keypoints whose rows are staged at a time in reference-order mode
+#ifndef SVO_SIA_STG
+#define SVO_SIA_STG 64
+#endif
+constexpr int SIA_STG = SVO_SIA_STG;    // keypoints whose rows are staged at a time in reference-order mode
 enum { KF_PX = 0, KF_PY, KF_PZ, KF_QX, KF_QY, KF_GXX, KF_GXY, KF_GYY, KF_ACT, KF_COUNT };
 enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
 struct SiaLds {
@@ -479,16 +483,27 @@ struct Sia {
                         const SVO_LDS(float)* pa = LDSCF(stage) + ia * PS;
                         const SVO_LDS(float)* pb = LDSCF(stage) + ib * PS;
                         // hessian += row^T row (lanes 0..20), residual += row * (-diff) (lanes 21..26):
-                        // one multiply and one add of the chain per patch pixel, in storage order
-                        for (int j = 0; j < m; j++) {
-                            const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + j * KS);
-                            const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + j * KS);
-                            const v4f a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-                            const v4f b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-                            eacc += a0.x * b0.x; eacc += a0.y * b0.y; eacc += a0.z * b0.z; eacc += a0.w * b0.w;
-                            eacc += a1.x * b1.x; eacc += a1.y * b1.y; eacc += a1.z * b1.z; eacc += a1.w * b1.w;
-                            eacc += a2.x * b2.x; eacc += a2.y * b2.y; eacc += a2.z * b2.z; eacc += a2.w * b2.w;
-                            eacc += a3.x * b3.x; eacc += a3.y * b3.y; eacc += a3.z * b3.z; eacc += a3.w * b3.w;
+                        // one multiply and one add of the chain per patch pixel, in storage order. The
+                        // rows of keypoint j + 1 are on their way from LDS while those of j are added.
+                        // Four keypoints per trip: their 32 LDS reads are in flight together and the chain
+                        // starts when the first arrive. (Slots past m up to the next multiple of four were
+                        // staged as zeros like every keypoint that takes no part: they add exact zeros.)
+                        for (int j = 0; j < m; j += 4) {
+                            v4f ra[4][4], rb[4][4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + (j + u) * KS);
+                                const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + (j + u) * KS);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) { ra[u][e] = qa[e]; rb[u][e] = qb[e]; }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    eacc += ra[u][e].x * rb[u][e].x; eacc += ra[u][e].y * rb[u][e].y;
+                                    eacc += ra[u][e].z * rb[u][e].z; eacc += ra[u][e].w * rb[u][e].w;
+                                }
                         }
                     }
                 }
@@ -534,7 +549,14 @@ struct Sia {
         }
         SIA_T(g2);
         float delta[6], pg[6];
+#ifdef SVO_SVD_ONE_LANE
+        // experiment: the solve under an exec mask of one lane (less switching power), result broadcast
+        if (lane == 0) gn_solve6(H, b, delta, exact);
+#pragma unroll
+        for (int q = 0; q < 6; q++) delta[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(delta[q])));
+#else
         gn_solve6(H, b, delta, exact);
+#endif
         exponential_map(delta, pg);
         mat33f_vec(pm.R, pg, grad);                  // pose_estimator.cpp:495-497
         mat33f_vec(pm.R, pg + 3, grad + 3);
@@ -740,7 +762,12 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     const bool batched = batch >= 32;
     int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
     if (batched && waves > 1 && waves < 8) waves /= 2;
-    int mode = batched ? 1 : 0;
+    int mode = 0;
+    // (experiments: SVO_SIA_MODE = 0 / 1 and SVO_SIA_WAVES = 1 / 2 / 4 / 8 force the shape of batched launches)
+    static const int env_mode = getenv("SVO_SIA_MODE") ? atoi(getenv("SVO_SIA_MODE")) : -1;
+    static const int env_waves = getenv("SVO_SIA_WAVES") ? atoi(getenv("SVO_SIA_WAVES")) : 0;
+    if (batched && env_mode >= 0 && env_mode <= 1) mode = env_mode;
+    if (batched && (env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8)) waves = env_waves;
     int T = 64 * waves;
     int cap = (nb + T - 1) / T * T;                   // every lane of every pass owns a slot
     size_t lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
