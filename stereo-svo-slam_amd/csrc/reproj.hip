@@ -19,7 +19,7 @@
 // computed redundantly by every lane (no broadcast, no barrier).
 #include "svo_kernels.hpp"
 #include <algorithm>
-#include <atomic>
+#include <mutex>
 
 namespace svo {
 
@@ -266,13 +266,13 @@ bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t
     const int cap = (std::max(n_bound, 1) + 255) & ~255;
     const size_t lds = (size_t)cap * 6 * sizeof(float);
     if (lds > 120 * 1024) return false;
-    static std::atomic<bool> configured{false};
-    if (!configured.exchange(true)) {
+    static std::once_flag configured;
+    std::call_once(configured, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    }
+    });
     if (n_bound <= 128)
         hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), lds, stream, d_args, cap);
     else

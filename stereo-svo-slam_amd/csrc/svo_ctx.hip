@@ -709,11 +709,17 @@ static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool fi
     }
     if (m == 0) return SVO_OK;
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));
+    // (a launch that fails must not be masked by the next one that succeeds: checked one by one)
     launch_compact(dargs_at<CompactArgs>(c, c->off_compact), m, c->cap, c->stream);
-    if (c->det_levels > 0)
+    HIP_TRY(hipGetLastError());
+    if (c->det_levels > 0) {
         launch_detect(dargs_at<DetectArgs>(c, c->off_det), m, c->max_cells, c->det_levels, c->stream);
+        HIP_TRY(hipGetLastError());
+    }
     launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), m, c->max_cells, c->stream);
+    HIP_TRY(hipGetLastError());
     launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), m, c->cap, c->stream);
+    HIP_TRY(hipGetLastError());
     launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), m, c->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
@@ -874,6 +880,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, first ? c->args_bytes : c->frame_args_bytes,
                            hipMemcpyHostToDevice, c->stream));
     launch_pyr_fused(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, mem != SVO_MEM_DEVICE_BORROW, c->stream);
+    HIP_TRY(hipGetLastError());   // (every launch is checked on its own: a later success must not mask a failure)
     std::vector<int> need(B, 0);
     if (first) {
         for (int s = 0; s < B; s++) {
@@ -885,6 +892,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     } else {
         SVO_MARK(1);
         launch_compact(dargs_at<CompactArgs>(c, c->off_compact), M, c->cap, c->stream);
+        HIP_TRY(hipGetLastError());
         SVO_MARK(2);
         // the compaction can only shrink a sequence's keypoint set, so last frame's counts bound the
         // grids and the alignment kernel's LDS working set
@@ -893,17 +901,21 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         grid_n = std::min(grid_n, c->cap);
         if (!launch_sia(dargs_at<SiaArgs>(c, c->off_sia), M, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream))
             return svo_set_error(SVO_ERR_CAPACITY, "sparse alignment: %d keypoints exceed the workspaces", grid_n);
+        HIP_TRY(hipGetLastError());
         SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), M, grid_n, c->cam.window_size_opt_flow, c->stream);
+        HIP_TRY(hipGetLastError());
         SVO_MARK(4);
         if (!launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), M, grid_n, c->stream))
             return svo_set_error(SVO_ERR_CAPACITY, "reprojection GN: %d keypoints do not fit LDS", grid_n);
+        HIP_TRY(hipGetLastError());
         SVO_MARK(5);
         launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->stream);
+        HIP_TRY(hipGetLastError());
         SVO_MARK(6);
         launch_filter(dargs_at<FilterArgs>(c, c->off_filt), M, c->stream);
-        SVO_MARK(7);
         HIP_TRY(hipGetLastError());
+        SVO_MARK(7);
         HIP_TRY(hipMemcpyAsync(c->h_inside, c->d_inside, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
         hlap(1);   // launches
         flush_pending(c);                 // previous frame's pose filter, overlapped with the kernels

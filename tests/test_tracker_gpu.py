@@ -209,7 +209,9 @@ def test_groups_and_pipelined_submit_equal_lockstep(monkeypatch):
         two.submit_packed(packs[k])
     two.wait()
     t1, t2 = one.totals(), two.totals()
-    assert (t1.frames, t1.keyframes, t1.keypoints) == (t2.frames, t2.keyframes, t2.keypoints)
+    detail = [(i, len(one.get_frame(i).kps2d), len(two.get_frame(i).kps2d), one.num_keyframes(i), two.num_keyframes(i),
+               len(one.get_keyframe(0, i).kps2d), len(two.get_keyframe(0, i).kps2d)) for i in range(5)]
+    assert (t1.frames, t1.keyframes, t1.keypoints) == (t2.frames, t2.keyframes, t2.keypoints), detail
     assert t2.n_groups == 2 and t2.launches == 2 * n_frames and t1.launches == n_frames
     for i in range(5):
         a, b = one.get_frame(i), two.get_frame(i)
