@@ -192,9 +192,11 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     __shared__ __attribute__((aligned(16))) uint8_t s_J[KLT_TJROWS * KLT_TJS];
     __shared__ long long s_part[KLT_WAVES][4];
 
-    const int kfid = a.kf_id ? G(a.kf_id)[kp] : 0;
+    // the keyframe record is wave-uniform: its fields are read where they are used. (A local copy of
+    // the struct lands in scratch memory — 216 B per lane written and read back per keypoint, 0.7 GB
+    // of HBM writes per 256-sequence launch — because lk[] is indexed with the run-time level.)
+    const int kfid = __builtin_amdgcn_readfirstlane(a.kf_id ? G(a.kf_id)[kp] : 0);
     SVO_GP(const KfDev) kfp = G(a.kfs) + kfid;
-    const KfDev kf = *kfp;            // (scalar loads: the record is wave-uniform)
 
     svo_kp2d ref;
     float nx, ny;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             q = project_point(pm.Rd, pm.t, camd, G(a.kps3d)[kp]);
         }
         nx = q.x; ny = q.y;
-        ref = G(kf.kps2d)[G(a.kp_index)[kp]];
+        ref = G(kfp->kps2d)[G(a.kp_index)[kp]];
         if (tid == 0) {
             G(a.proj_out)[kp] = q;
             if (a.ref_out) G(a.ref_out)[kp] = ref;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         nx = q.x; ny = q.y;
     }
 
-    const int maxLevel = min(kf.n_lk, a.n_cur) - 1;
+    const int maxLevel = min(kfp->n_lk, a.n_cur) - 1;
     const float halfWin = (win - 1) * 0.5f;
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     const bool col_on = row_on && lc < win;
 
     for (int level = maxLevel; level >= 0; level--) {
-        const ImgView I = kf.lk[level];
+        const ImgView I = kfp->lk[level];
         const ImgView J = a.cur[level];
         const float lscale = (float)(1. / (1 << level));
         float prevx = ref.x * lscale, prevy = ref.y * lscale;

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs*
     if (tid == 0) {
         for (int j = 0; j < 6; j++) G(a.pose_out)[j] = x0[j];
         if (a.cost_out) *G(a.cost_out) = prev_cost;
+        if (a.zero_out) *G(a.zero_out) = 0;
         if (a.trace) {
             svo_gn_trace t;
             t.level = 0; t.n_gradient = n_grad; t.n_cost = n_cost; t.n_accepted = accepted;

@@ -121,12 +121,12 @@ __constant__ int8_t c_tri_c[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 
 // with row = field * 16 + pixel (fields REC_*), rows 64..66 = sum gxgx, gxgy, gygy.
 constexpr int SIA_REC_ROWS = 68;
 
-__global__ __launch_bounds__(256) void sia_prep_kernel(const SiaArgs* __restrict__ args) {
+__global__ __launch_bounds__(64) void sia_prep_kernel(const SiaArgs* __restrict__ args) {
     const SiaArgs& a = args[blockIdx.z];
     const int n = min(*G(a.n_ptr), a.rec_cap);
     const int level = a.cam.min_pyramid_level_pose_estimation + blockIdx.y;
     if (level >= a.cam.max_pyramid_levels) return;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 64 + threadIdx.x;      // single-wave workgroups: they fit any free slot
     const int kp = idx >> 4, px = idx & 15;
     const int span = (n + 3) & ~3;                       // the consumer copies float4 columns
     if (kp >= span) return;                              // (whole 16-lane rows leave together)
@@ -775,13 +775,14 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     // workgroups per CU instead of one); measured +5 % frames/s on the 768-sequence bench against
     // MODE 0, and one wave per 64 keypoints beats half as many waves with two passes each
     const bool batched = batch >= 32;
-    int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8;
+    // (at most 4 waves: with 8 a wave may only hold 256 registers and the kernel spills ~80 into scratch)
+    int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : 4;
     int mode = batched ? 1 : 0;
-    // (experiments: SVO_SIA_MODE = 0 / 1 and SVO_SIA_WAVES = 1 / 2 / 4 / 8 force the shape of batched launches)
+    // (experiments: SVO_SIA_MODE = 0 / 1 / 2 and SVO_SIA_WAVES = 1 / 2 / 4 force the shape of batched launches)
     static const int env_mode = getenv("SVO_SIA_MODE") ? atoi(getenv("SVO_SIA_MODE")) : -1;
     static const int env_waves = getenv("SVO_SIA_WAVES") ? atoi(getenv("SVO_SIA_WAVES")) : 0;
     if (batched && env_mode >= 0 && env_mode <= 2) mode = env_mode;
-    if (batched && (env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8)) waves = env_waves;
+    if (batched && (env_waves == 1 || env_waves == 2 || env_waves == 4)) waves = env_waves;
     int T = 64 * waves;
     int cap = (nb + T - 1) / T * T;                   // every lane of every pass owns a slot
     size_t lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
@@ -790,16 +791,16 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
         lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
     }
     if (lds > SIA_LDS_BUDGET && mode != 2) {
-        mode = 2; waves = 8; T = 512;
+        mode = 2; waves = 4; T = 256;
         cap = (nb + T - 1) / T * T;
         lds = sia_lds_layout(img, cap, T, exact != 0, mode).total;
     }
     if (lds > SIA_LDS_BUDGET || cap > rec_cap) return false;
-    hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 255) / 256, n_lv, batch), dim3(256), 0, stream, d_args);
+    hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 63) / 64, n_lv, batch), dim3(64), 0, stream, d_args);
 #define SIA_CASE(W, M) if (waves == W && mode == M) { sia_launch_shape<W, M>(d_args, batch, img, cap, lds, stream); return true; }
-    SIA_CASE(1, 0) SIA_CASE(2, 0) SIA_CASE(4, 0) SIA_CASE(8, 0)
-    SIA_CASE(1, 1) SIA_CASE(2, 1) SIA_CASE(4, 1) SIA_CASE(8, 1)
-    SIA_CASE(1, 2) SIA_CASE(2, 2) SIA_CASE(4, 2) SIA_CASE(8, 2)
+    SIA_CASE(1, 0) SIA_CASE(2, 0) SIA_CASE(4, 0)
+    SIA_CASE(1, 1) SIA_CASE(2, 1) SIA_CASE(4, 1)
+    SIA_CASE(1, 2) SIA_CASE(2, 2) SIA_CASE(4, 2)
 #undef SIA_CASE
     return false;
 }

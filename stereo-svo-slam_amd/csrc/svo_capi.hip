@@ -380,7 +380,7 @@ extern "C" int svo_depth_filter_update(svo_handle* h, const svo_kp2d* kps2d, svo
     FilterArgs* d;
     rc = stage(h, fa, &d);
     if (rc) return rc;
-    launch_filter(d, 1, h->stream);
+    launch_filter(d, 1, n, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

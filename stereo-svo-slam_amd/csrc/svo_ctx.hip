@@ -858,6 +858,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             ra->tracked = q.tracked; ra->err = q.klt_err; ra->pose_in = dr->pose_sia;
             ra->pose_out = dr->pose_refined; ra->cost_out = &dr->reproj_cost; ra->trace = &dr->reproj_trace;
             ra->exact_pinv = c->exact_pinv;
+            ra->zero_out = c->d_inside + s;      // filter_update_kernel adds to it
             SsdArgs* ss = args_at<SsdArgs>(c, c->off_ssd, slot);
             std::memset(ss, 0, sizeof(*ss));
             ss->left = q.cur_set->left[0]; ss->right = q.cur_set->right; ss->n_ptr = k.n;
@@ -913,7 +914,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->stream);
         HIP_TRY(hipGetLastError());
         SVO_MARK(6);
-        launch_filter(dargs_at<FilterArgs>(c, c->off_filt), M, c->stream);
+        launch_filter(dargs_at<FilterArgs>(c, c->off_filt), M, grid_n, c->stream);
         HIP_TRY(hipGetLastError());
         SVO_MARK(7);
         HIP_TRY(hipMemcpyAsync(c->h_inside, c->d_inside, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));

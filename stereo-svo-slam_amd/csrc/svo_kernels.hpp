@@ -105,6 +105,7 @@ struct ReprojArgs {
     float* cost_out;
     svo_gn_trace* trace;          // [1] or null
     int exact_pinv;
+    int* zero_out;                // or null: set to 0 (the inside counter filter_update_kernel adds to)
 };
 bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t stream);   // false: too many keypoints
 
@@ -150,6 +151,6 @@ struct FilterArgs {
     int width, height;
     int* inside_count;            // keyframe_needed numerator (or null)
 };
-void launch_filter(const FilterArgs* d_args, int batch, hipStream_t stream);
+void launch_filter(const FilterArgs* d_args, int batch, int max_n, hipStream_t stream);   // inside_count must be zero
 
 }  // namespace svo
