@@ -24,6 +24,12 @@ import os
 import sys
 import time
 
+# The ctx drives every sequence group on its own HIP stream; the HIP runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise. Six
+# groups need more: set before anything initialises HIP (a deployment sets it the same way,
+# INTEGRATION.md section 5).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "stereo-svo-slam_amd")):
     if p not in sys.path:
@@ -40,7 +46,7 @@ WORKLOAD_LABEL = {"euroc": "EuRoC MH_02 class (C2)", "blender": "Blender classro
                   "hd": "synthetic roofline case (C3)", "econ": "Econ Tara class, distorted (C5)", "tiny": "test size"}
 KERNEL_OF_STAGE = {"sparse_align": "sia_gn_kernel", "klt": "klt_track_kernel",
                    "reproj_gn": "reproj_gn_kernel", "ssd_disparity": "ssd_disparity_kernel",
-                   "filter_update": "filter_update_kernel", "images+pyramids": "pyr_halfsample_kernel"}
+                   "filter_update": "filter_update_kernel", "images+pyramids": "pyr_fused_kernel"}
 STAGES = ("images+pyramids", "compaction", "sparse_align", "klt", "reproj_gn", "ssd_disparity",
           "filter_update", "keyframe+readback")
 KERNEL_STAGES = ("sparse_align", "klt", "reproj_gn", "ssd_disparity", "filter_update", "images+pyramids")
@@ -178,8 +184,8 @@ def main():
                     help="the timed region of exactly --steps steps is measured this many times in a row; "
                          "value = median")
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--seqs", type=int, default=768,
-                    help="sequences per GPU (default 768 = three groups of 256)")
+    ap.add_argument("--seqs", type=int, default=1536,
+                    help="sequences per GPU (default 1536 = six groups of 256 on six streams)")
     ap.add_argument("--fast", action="store_true",
                     help="svo_ctx_set_fast_solver(1) for the timed region: tree-ordered normal equations + LDL^T "
                          "instead of the default reference-order Gauss-Newton (bit-exact traces)")

@@ -75,7 +75,6 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     __shared__ __attribute__((aligned(16))) uint8_t s_t[(SSD_MAX_WIN + 1) * SSD_T_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t s_r[SSD_R_ROWS * SSD_R_STRIDE];
     __shared__ int s_w[SSD_MAX_MH * SSD_W_STRIDE];
-    __shared__ int s_m[SSD_MAX_MATCH];
     __shared__ int s_tt[4];
     __shared__ unsigned long long s_key[SSD_THREADS / 64];
     __shared__ int s_sum[SSD_THREADS / 64], s_cnt[SSD_THREADS / 64];
@@ -189,7 +188,11 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     }
     __syncthreads();
 
-    // ---- window sums of R^2: rows of W, 8 sliding segments per map row -> s_m
+    // ---- window sums of R^2: rows of W, 8 sliding segments per map row -> s_m. The match map takes
+    // the place of the search region, which nobody reads after the barrier above (17.4 KB of LDS per
+    // workgroup instead of 21.7: one more workgroup fits beside the alignment kernel's on a CU)
+    static_assert(sizeof(int) * SSD_MAX_MATCH <= SSD_R_ROWS * SSD_R_STRIDE, "match map must fit the region tile");
+    int* const s_m = reinterpret_cast<int*>(s_r);
     {
         const int seg_len = (mw + 7) >> 3;
         for (int item = tid; item < mh * 8; item += SSD_THREADS) {

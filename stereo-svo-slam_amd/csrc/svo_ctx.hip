@@ -1241,11 +1241,15 @@ svo_ctx::Worker* ctx_locate(svo_ctx* c, int seq, int* local) {
 extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
                               int device, svo_ctx** out) {
     if (!cam || !out || n_sequences < 1) return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
-    // SVO_GROUPS: number of independently driven groups. Default: groups of ~256 sequences (one
-    // alignment workgroup per CU), at least two from 64 sequences on. Measured on MI355X, 752x480:
-    // 256 sequences 129 K frames/s as one group, 153 K as two; 512: 173 K (2) / 176 K (3);
-    // 768: 188 K (3) / 169 K (4); 1024: 176 K (4).
+    // SVO_GROUPS: number of independently driven groups. Default: groups of ~256 sequences, at least
+    // two from 64 sequences on, and one fewer than the hardware queues the HIP runtime uses
+    // (GPU_MAX_HW_QUEUES, default 4): streams beyond that share a queue and serialise. Measured on
+    // MI355X, 752x480, frames/s: 768 sequences 149 K as 3 groups, 106 K as 4, 119 K as 6 with 4
+    // queues; with GPU_MAX_HW_QUEUES=8: 768 / 3 groups 154 K, 1024 / 4 162 K, 1536 / 6 170 K.
+    int hwq = 4;
+    if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) hwq = std::max(2, std::atoi(e));
     int G = n_sequences >= 64 ? std::max(2, (n_sequences + 128) / 256) : 1;
+    G = std::min(G, hwq - 1);
     if (const char* e = std::getenv("SVO_GROUPS")) G = std::atoi(e);
     G = std::max(1, std::min(G, std::min(n_sequences, 16)));
     svo_ctx* c = new (std::nothrow) svo_ctx();
