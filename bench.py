@@ -25,10 +25,10 @@ import sys
 import time
 
 # The ctx drives every sequence group on its own HIP stream; the HIP runtime maps streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise. Six
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise. Eight
 # groups need more: set before anything initialises HIP (a deployment sets it the same way,
 # INTEGRATION.md section 5).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "stereo-svo-slam_amd")):
@@ -184,8 +184,8 @@ def main():
                     help="the timed region of exactly --steps steps is measured this many times in a row; "
                          "value = median")
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--seqs", type=int, default=1536,
-                    help="sequences per GPU (default 1536 = six groups of 256 on six streams)")
+    ap.add_argument("--seqs", type=int, default=2048,
+                    help="sequences per GPU (default 2048 = eight groups of 256 on eight streams)")
     ap.add_argument("--fast", action="store_true",
                     help="svo_ctx_set_fast_solver(1) for the timed region: tree-ordered normal equations + LDL^T "
                          "instead of the default reference-order Gauss-Newton (bit-exact traces)")

@@ -23,11 +23,13 @@
 
 namespace svo {
 
-constexpr int RP_CHUNK = 256;     // keypoints staged per step
 
-struct ReprojShared {
-    float tbuf[2][RP_CHUNK];      // cost terms of a chunk, keypoint order (double buffered)
-    float js[14][RP_CHUNK];       // J (2x6), diff (2) of a chunk
+// CH keypoints are staged per step: one per thread (4 KB of LDS for the one-wave shape, 16 KB for
+// four waves — LDS is what the window kernels of other sequence groups are short of)
+template <int CH>
+struct alignas(16) ReprojShared {
+    float tbuf[2][CH];            // cost terms of a chunk, keypoint order (double buffered)
+    float js[14][CH];             // J (2x6), diff (2) of a chunk
     float sums[28];
 };
 
@@ -49,8 +51,8 @@ __device__ inline void rp_sync() {
 
 // cost of PoseRefinerCallback::do_calc
 template <int WAVES>
-__device__ float reproj_cost(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared& sh, int& par) {
-    constexpr int T = 64 * WAVES;
+__device__ float reproj_cost(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared<64 * WAVES>& sh, int& par) {
+    constexpr int T = 64 * WAVES, RP_CHUNK = T;
     const int tid = threadIdx.x;
     PoseMats pm;
     pose_mats(pose, pm);
@@ -81,8 +83,8 @@ __device__ float reproj_cost(const ReprojArgs& a, const RpKps& kp, int n, const 
 
 // get_gradient at `pose`: leaves the step in grad[6] (every lane)
 template <int WAVES>
-__device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared& sh, float grad[6]) {
-    constexpr int T = 64 * WAVES;
+__device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, const float pose[6], ReprojShared<64 * WAVES>& sh, float grad[6]) {
+    constexpr int T = 64 * WAVES, RP_CHUNK = T;
     const int tid = threadIdx.x;
     PoseMats pm;
     pose_mats(pose, pm);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs*
     const ReprojArgs& a = args[blockIdx.x];
     const int n = min(*G(a.n_ptr), cap);
     const int tid = threadIdx.x;
-    __shared__ ReprojShared sh;
+    __shared__ ReprojShared<T> sh;
     extern __shared__ __attribute__((aligned(16))) float rp_dyn[];
     const RpKps kp{(SVO_LDS(float)*)rp_dyn, cap};
 
@@ -264,7 +266,8 @@ void launch_project(const float* pose, const svo_kp3d* kps3d, int n, const svo_c
 // 24 B each). One wave per sequence up to 128 keypoints, four beyond. Returns false when the
 // keypoints do not fit LDS (more than ~5000).
 bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t stream) {
-    const int cap = (std::max(n_bound, 1) + 255) & ~255;
+    const int T = n_bound <= 128 ? 64 : 256;
+    const int cap = (std::max(n_bound, 1) + T - 1) / T * T;          // whole staging steps
     const size_t lds = (size_t)cap * 6 * sizeof(float);
     if (lds > 120 * 1024) return false;
     static std::once_flag configured;

@@ -90,7 +90,7 @@ __host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, 
     l.tbuf = off;  off += T == 64 ? 0 : (size_t)2 * cap * 4;             // one wave sums by v_readlane
     l.kpf = off;   off += mode == 2 ? 0 : (size_t)KF_COUNT * cap * 4;
     l.rec = off;   off += mode == 2 ? 0 : (size_t)(mode == 1 ? 16 : 64) * cap * 4;
-    l.sums = off;  off += 16 * 32 * 4;                                 // [WAVES <= 16][32]
+    l.sums = off;  off += (size_t)(T / 64) * 32 * 4;                   // [WAVES][32]
     l.stage = off; off += exact ? (size_t)7 * (SIA_STG * 20 + 4) * 4 : 0;   // 7 planes of SIA_STG keypoints' rows (20 floats each)
     l.total = off;
     return l;
@@ -766,13 +766,16 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     const int nb = std::max(n_bound, 1);
     const int n_lv = cam.max_pyramid_levels - cam.min_pyramid_level_pose_estimation;
     const int img = sia_img_bytes(cam, width, height);
-    // many sequences (batched): the records only get_gradient needs stay in HBM / L2 (MODE 1, two
-    // workgroups per CU instead of one); measured +5 % frames/s on the 768-sequence bench against
-    // MODE 0, and one wave per 64 keypoints beats half as many waves with two passes each
-    const bool batched = batch >= 32;
+    // A batch of sequences: records, per-keypoint values and image taps from L2 (MODE 2) and one
+    // wave per 128 keypoints, i.e. ~38 KB of LDS per sequence (the staging area of the ordered
+    // accumulation) instead of 74-96 KB. With six and more sequence groups in flight LDS is what the
+    // window kernels (SSD 17 KB, pyramid 15 KB, KLT 10 KB per workgroup) run short of: 1536 sequences
+    // in 6 groups, frames/s: MODE 0 174 K, MODE 1 184 K, MODE 2 two waves 200 K, one wave 206 K.
     // (at most 4 waves: with 8 a wave may only hold 256 registers and the kernel spills ~80 into scratch)
+    const bool batched = batch >= 32;
     int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : 4;
-    int mode = batched ? 1 : 0;
+    int mode = 0;
+    if (batched) { mode = 2; waves = nb <= 128 ? 1 : nb <= 256 ? 2 : 4; }
     // (experiments: SVO_SIA_MODE = 0 / 1 / 2 and SVO_SIA_WAVES = 1 / 2 / 4 force the shape of batched launches)
     static const int env_mode = getenv("SVO_SIA_MODE") ? atoi(getenv("SVO_SIA_MODE")) : -1;
     static const int env_waves = getenv("SVO_SIA_WAVES") ? atoi(getenv("SVO_SIA_WAVES")) : 0;

@@ -6,4 +6,4 @@ import os as _os
 # A ctx with more than three sequence groups needs more than the HIP runtime's default of four
 # hardware queues (streams that share a queue serialise). Only effective before HIP initialises;
 # an explicit setting of the caller wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")

@@ -186,6 +186,33 @@ def test_batch_equals_single():
             assert np.array_equal(a.info, b.info)
 
 
+def test_batched_launch_shapes_equal_single(monkeypatch):
+    """From 32 sequences per group on, the alignment kernel changes shape (records, per-keypoint
+    values and image taps from L2, half as many waves): same arithmetic in the same order, so a
+    sequence inside such a group ends bit for bit like a ctx of its own (which the other tests pin
+    to the oracle). (Default solver: the fast solver's tree sums depend on the number of waves.)"""
+    monkeypatch.setenv("SVO_GROUPS", "1")
+    n_seq, n_frames = 34, 5
+    seqs = [synth.make_sequence("tiny", n_frames, 40 + (s % 6), device="cpu") for s in range(n_seq)]
+    cfg = seqs[0][0]
+    batch = StereoSlamBatch(cfg, cfg["width"], cfg["height"], n_seq)
+    assert batch.groups() == 1
+    for k in range(n_frames):
+        batch.new_images([s[1][k].numpy() for s in seqs], [s[2][k].numpy() for s in seqs],
+                         [float(s[4][k]) for s in seqs])
+    for i in (0, 5, 33):
+        one = StereoSlam(cfg)
+        for k in range(n_frames):
+            one.new_image(seqs[i][1][k].numpy(), seqs[i][2][k].numpy(), float(seqs[i][4][k]))
+        a, b = batch.get_frame(i), one.get_frame()
+        assert np.array_equal(a.pose, b.pose), (i, a.pose, b.pose)
+        assert np.array_equal(a.kps2d, b.kps2d) and np.array_equal(a.kps3d, b.kps3d)
+        assert np.array_equal(a.info, b.info)
+        assert np.array_equal(batch.get_trajectory(i), one.get_trajectory())
+        one.close()
+    batch.close()
+
+
 def test_groups_and_pipelined_submit_equal_lockstep(monkeypatch):
     """Sequence groups (own stream + host thread each) and svo_submit_images / svo_wait give
     the results of the single-group, call-per-frame form: 5 sequences as 1 group vs 2 groups
