@@ -193,7 +193,8 @@ def test_batched_launch_shapes_equal_single(monkeypatch):
     to the oracle). (Default solver: the fast solver's tree sums depend on the number of waves.)"""
     monkeypatch.setenv("SVO_GROUPS", "1")
     n_seq, n_frames = 34, 5
-    seqs = [synth.make_sequence("tiny", n_frames, 40 + (s % 6), device="cpu") for s in range(n_seq)]
+    six = [synth.make_sequence("tiny", n_frames, 40 + s, device="cpu") for s in range(6)]
+    seqs = [six[s % 6] for s in range(n_seq)]
     cfg = seqs[0][0]
     batch = StereoSlamBatch(cfg, cfg["width"], cfg["height"], n_seq)
     assert batch.groups() == 1
