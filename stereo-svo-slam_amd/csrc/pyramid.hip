@@ -96,20 +96,34 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const PyrArgs* __restric
         const bool aligned = ((reinterpret_cast<uintptr_t>(src.data) | (uintptr_t)src.stride) & 3) == 0;
         const int rows = n_lk > 1 ? PF_ROWS : PF_T;              // no halo rows without an LK pyramid
         const int r_lo = n_lk > 1 ? 0 : PF_HALO;
-        for (int i = tid; i < rows * (PF_LS / 4); i += 256) {
-            const int r = r_lo + i / (PF_LS / 4), d = i % (PF_LS / 4);
-            const int gy = reflect101(y0 - PF_HALO + r, src.h);
-            const uint8_t* row = src.g() + (size_t)gy * src.stride;
-            const int x = x0 - PF_X0 + 4 * d;
-            uint32_t v;
-            if (aligned && x >= 0 && x + 4 <= src.w) {
-                v = *reinterpret_cast<const uint32_t*>(row + x);
-            } else {
-                v = 0;
+        // every thread's (up to) six dwords are requested before the first is stored: one round trip
+        // to HBM per tile instead of six
+        constexpr int NIT = (PF_ROWS * (PF_LS / 4) + 255) / 256;
+        uint32_t v[NIT];
 #pragma unroll
-                for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x + b, src.w)] << (8 * b);
+        for (int u = 0; u < NIT; u++) {
+            const int i = tid + 256 * u;
+            v[u] = 0;
+            if (i < rows * (PF_LS / 4)) {
+                const int r = r_lo + i / (PF_LS / 4), d = i % (PF_LS / 4);
+                const int gy = reflect101(y0 - PF_HALO + r, src.h);
+                const uint8_t* row = src.g() + (size_t)gy * src.stride;
+                const int x = x0 - PF_X0 + 4 * d;
+                if (aligned && x >= 0 && x + 4 <= src.w) {
+                    v[u] = *reinterpret_cast<const uint32_t*>(row + x);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v[u] |= (uint32_t)row[reflect101(x + b, src.w)] << (8 * b);
+                }
             }
-            *reinterpret_cast<uint32_t*>(&t0[r * PF_LS + 4 * d]) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int i = tid + 256 * u;
+            if (i < rows * (PF_LS / 4)) {
+                const int r = r_lo + i / (PF_LS / 4), d = i % (PF_LS / 4);
+                *reinterpret_cast<uint32_t*>(&t0[r * PF_LS + 4 * d]) = v[u];
+            }
         }
     }
     __syncthreads();
