@@ -359,6 +359,8 @@ __host__ __device__ inline void jacobi_svd(float (&At)[N][M], float (&W)[N], flo
 // that every array index is a compile-time constant (all loops over rows / columns / pairs are
 // unrolled, the selection sort swaps under predicates): At, Vt and W live in registers instead of
 // scratch memory. Same operations in the same order as jacobi_svd<6,6>: same bits.
+// (The product of two floats is exact in double, so fma(x, y, acc) == acc + x * y bit for bit: the
+// sums of squares and the dot products below use one instruction per term.)
 __device__ inline void jacobi_svd6_reg(float (&At)[6][6], float (&W)[6], float (&Vt)[6][6]) {
     const float eps = FLT_EPSILON * 2;
     double Wd[6];
@@ -366,7 +368,7 @@ __device__ inline void jacobi_svd6_reg(float (&At)[6][6], float (&W)[6], float (
     for (int i = 0; i < 6; i++) {
         double sd = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd = __builtin_fma((double)t, (double)t, sd); }
         Wd[i] = sd;
 #pragma unroll
         for (int k = 0; k < 6; k++) Vt[i][k] = (i == k) ? 1.f : 0.f;
@@ -379,26 +381,31 @@ __device__ inline void jacobi_svd6_reg(float (&At)[6][6], float (&W)[6], float (
             for (int j = i + 1; j < 6; j++) {
                 double a = Wd[i], p = 0, b = Wd[j];
 #pragma unroll
-                for (int k = 0; k < 6; k++) p += (double)At[i][k] * At[j][k];
-                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                for (int k = 0; k < 6; k++) p = __builtin_fma((double)At[i][k], (double)At[j][k], p);
+                // |p| <= eps * sqrt(a*b) of the reference, decided without the square root whenever
+                // p^2 and eps^2 a b are further apart than any rounding error of either side (1e-9
+                // relative, the errors are ~1e-16); the exact expression decides the rest (and NaNs)
+                const double pp = p * p, ee = ((double)eps * (double)eps) * (a * b);
+                bool rotate = pp > ee * (1 + 1e-9);
+                if (!rotate && !(pp < ee * (1 - 1e-9))) rotate = !(fabs(p) <= eps * sqrt(a * b));
+                if (rotate) {
                     p *= 2;
                     const double beta = a - b, gamma = svo_hypot(p, beta);
-                    float c, s;
-                    if (beta < 0) {
-                        const double delta = (gamma - beta) * 0.5;
-                        s = (float)sqrt(delta / gamma);
-                        c = (float)(p / (gamma * s * 2));
-                    } else {
-                        c = (float)sqrt((gamma + beta) / (gamma * 2));
-                        s = (float)(p / (gamma * c * 2));
-                    }
+                    // beta < 0: s = sqrt((gamma - beta) / 2 / gamma), c = p / (2 gamma s); else c and s swap
+                    // roles with (gamma + beta) / (2 gamma): one square root and one division serve both
+                    const bool neg = beta < 0;
+                    const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
+                    const double den = neg ? gamma : gamma * 2;
+                    const float r1 = (float)sqrt(num / den);
+                    const float r2 = (float)(p / (gamma * r1 * 2));
+                    const float c = neg ? r2 : r1, s = neg ? r1 : r2;
                     a = b = 0;
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         const float t0 = c * At[i][k] + s * At[j][k];
                         const float t1 = -s * At[i][k] + c * At[j][k];
                         At[i][k] = t0; At[j][k] = t1;
-                        a += (double)t0 * t0; b += (double)t1 * t1;
+                        a = __builtin_fma((double)t0, (double)t0, a); b = __builtin_fma((double)t1, (double)t1, b);
                     }
                     Wd[i] = a; Wd[j] = b;
                     changed = true;
@@ -416,7 +423,7 @@ __device__ inline void jacobi_svd6_reg(float (&At)[6][6], float (&W)[6], float (
     for (int i = 0; i < 6; i++) {
         double sd = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd += (double)t * t; }
+        for (int k = 0; k < 6; k++) { const float t = At[i][k]; sd = __builtin_fma((double)t, (double)t, sd); }
         Wd[i] = sqrt(sd);
     }
     // selection sort, largest first: row i <-> the first maximum of rows i..5
