@@ -6,7 +6,8 @@ sequence a rank owns: pyramids -> sparse image alignment -> KLT -> reprojection
 GN -> SSD disparity -> depth filter (+ keyframe creation when it is due), on
 frames that are already resident in HBM. Workload at N=1: BASELINE.json
 configs[1] — EuRoC MH_02 class 752x480 stereo, 4-level SIA pyramid (6/2),
-~130-200 patches per frame — as seeded synthetic sequences (no dataset ships).
+~110-200 patches per frame — as seeded synthetic sequences (no dataset ships),
+2048 sequences per GPU in 8 sequence groups (weak scaling: the same per rank).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
