@@ -196,15 +196,16 @@ __global__ __launch_bounds__(64) void sia_prep_kernel(const SiaArgs* __restrict_
 #endif
 
 // MODE — where the working set of a sequence lives (same arithmetic, same order in all three):
-//   0 (a few sequences, latency matters): level image, per-keypoint values and all records in LDS;
-//   1 (a batch of sequences): image, per-keypoint values and the cost records (i1) in LDS, the
-//     records only get_gradient needs (reference patch sums, image gradients, sum g g^T: 3/4 of
-//     the bytes) are read where sia_prep_kernel wrote them — ~45 KB of LDS per sequence instead
-//     of ~100 KB, so the workgroup finds room on a CU that another sequence group's window
-//     kernels are filling;
-//   2 (BIG: keypoint sets / level images that do not fit LDS, the 1920x1080 configuration with
-//     ~1700 keypoints and a 480x270 finest level): per-keypoint values in the HBM workspace
-//     SiaArgs::kp_ws, records and image taps from L2.
+//   0 (a few sequences, latency matters): level image, per-keypoint values and all records in LDS
+//     (~100 KB);
+//   1 (the step between the two, when MODE 0 does not fit): image, per-keypoint values and the cost
+//     records (i1) in LDS, the records only get_gradient needs (reference patch sums, image
+//     gradients, sum g g^T: 3/4 of the bytes) are read where sia_prep_kernel wrote them;
+//   2 (a batch of sequences — LDS is what the window kernels of the other sequence groups run
+//     short of — and keypoint sets / level images that do not fit LDS, the 1920x1080 configuration
+//     with ~1700 keypoints and a 480x270 finest level): per-keypoint values in the HBM workspace
+//     SiaArgs::kp_ws, records and image taps from L2; LDS holds only the staging area of the
+//     ordered accumulation (~38 KB).
 template <int WAVES, int MODE>
 struct Sia {
     static constexpr bool BIG = MODE == 2;
