@@ -192,3 +192,25 @@ def test_bench_algorithmic_bytes_follow_design_section_5():
     assert ab["klt"] == n * 3 * 2 * 33 * 33 + 21 * n
     assert ab["ssd_disparity"] == n * (31 * 31 + (31 + 60) * (31 + 12)) + 12 * n
     assert ab["reproj_gn"] == 24 * n and ab["filter_update"] == 64 * n
+
+
+def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path):
+    """profiles/r02_pmc.json (read by bench.py for roofline.binding_roof) is what
+    tools/make_pmc_json.py derives from the committed counter and kernel-stats CSVs."""
+    import json, shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    for name in ("pmc_sq.csv", "kernel_stats.csv", "pmc.json"):
+        shutil.copy(os.path.join(prof, "r02_" + name), tmp_path / name)
+    out = tmp_path / "out"
+    out.mkdir()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_pmc_json.py"), str(tmp_path), str(out),
+                           "reclassify"], stdout=subprocess.DEVNULL)
+    new = json.load(open(out / "pmc.json"))
+    old = json.load(open(os.path.join(prof, "r02_pmc.json")))
+    assert new["seqs"] == old["seqs"] == 2048 and new["groups"] == old["groups"] == 8
+    assert set(new["kernels"]) == set(old["kernels"]) and "sia_gn_kernel" in new["kernels"]
+    for k, v in new["kernels"].items():
+        assert v["bound"] == old["kernels"][k]["bound"]
+        assert abs(v["frac"] - old["kernels"][k]["frac"]) < 1e-9
+    assert new["kernels"]["sia_gn_kernel"]["bound"] == "latency"
