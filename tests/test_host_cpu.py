@@ -16,6 +16,14 @@ import torch
 from stereo_svo_slam_amd import hip_lib, multi_seq, synth
 import util
 
+
+def _free_port():
+    """a TCP port nobody listens on right now (the rendezvous of the two-rank tests)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -122,10 +130,11 @@ def test_two_rank_gloo_run(tmp_path):
     """world_size 2 over gloo: barrier/max timing, sharding by sequence, one all_gather."""
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\n" + WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-                          "29611", str(script)], env=env, capture_output=True, text=True, timeout=600)
+                          port, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)

@@ -11,6 +11,15 @@ from stereo_svo_slam_amd import synth
 from stereo_svo_slam_amd.stereo_slam import StereoSlam, StereoSlamBatch
 import util
 
+
+def _free_port():
+    """a TCP port nobody listens on right now (the rendezvous of the two-rank tests)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 pytestmark = pytest.mark.gpu
 
 INT_FIELDS = ("level", "type", "keyframe_id", "keypoint_index", "ignore_during_refinement",
@@ -320,10 +329,11 @@ def test_two_ranks_share_the_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {root!r}\n" + TWO_RANK_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1",
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
