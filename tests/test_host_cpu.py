@@ -223,3 +223,30 @@ def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path):
         assert v["bound"] == old["kernels"][k]["bound"]
         assert abs(v["frac"] - old["kernels"][k]["frac"]) < 1e-9
     assert new["kernels"]["sia_gn_kernel"]["bound"] == "latency"
+
+
+def test_timeline_tool_on_a_synthetic_trace(tmp_path):
+    """tools/timeline.py (the overlap summary behind profiles/r02_timeline_*.txt) on a hand-made
+    kernel trace: two queues, every alignment kernel overlapped by the other queue's."""
+    import csv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows, t = [], 0
+    for _ in range(40):
+        for q in (1, 2):
+            s0 = t + q * 10
+            rows.append(dict(Start_Timestamp=s0, End_Timestamp=s0 + 500, Queue_Id=q,
+                             Kernel_Name="void svo::sia_gn_kernel<1, 2>(svo::SiaArgs const*, int, int)"))
+            rows.append(dict(Start_Timestamp=s0 + 600, End_Timestamp=s0 + 800, Queue_Id=q,
+                             Kernel_Name="void svo::klt_track_kernel<32>(svo::KltArgs const*)"))
+        t += 1000
+    path = tmp_path / "trace.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), str(path), "0.5"],
+                         capture_output=True, text=True, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("void sia_gn_kernel<1, 2>")][0].split()
+    assert abs(float(line[-4]) - 0.5) < 1e-6           # avg us of the 500 ns kernels
+    assert 0.9 < float(line[-1]) <= 1.0                # ~one other kernel in flight the whole time
+    assert "queue 1:" in out and "queue 2:" in out and "kernels in flight" in out
