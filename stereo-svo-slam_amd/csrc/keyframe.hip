@@ -19,6 +19,7 @@
 //    stereo_slam.cpp:157-159 and :237-245.
 #include "svo_kernels.hpp"
 #include "svo_tracker.hpp"
+#include <cstdlib>
 
 namespace svo {
 
@@ -101,7 +102,9 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
 // Small sets run with 256 threads: a 16-wave workgroup only starts on a CU that has drained, and
 // next to the other sequence groups' window kernels it waited ~0.4 ms for one (HIP events).
 void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t stream) {
-    hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(cap <= 1024 ? 256 : 1024), 0, stream, d_args);
+    static const int env_threads = getenv("SVO_COMPACT_THREADS") ? atoi(getenv("SVO_COMPACT_THREADS")) : 0;   // (experiments)
+    const int threads = env_threads >= 64 && env_threads <= 1024 && env_threads % 64 == 0 ? env_threads : (cap <= 1024 ? 256 : 1024);
+    hipLaunchKernelGGL(compact_kernel, dim3(batch), dim3(threads), 0, stream, d_args);
 }
 
 // --------------------------------------------------------------- detection

@@ -1163,19 +1163,24 @@ struct svo_ctx {
         bool busy = false, stop = false;
         int err = SVO_OK;
         std::string msg;
+        std::atomic<bool>* ctx_failed = nullptr;
     };
     int B = 0, device = 0;
+    // A frame that fails in ONE group leaves the ctx's sequences at mixed frame ids: the failure is
+    // latched here, the other groups drop what is still queued, and later submits are rejected.
+    std::atomic<bool> failed{false};
     std::vector<std::unique_ptr<Worker>> workers;
 };
 
 namespace {
 
 void worker_run_job(svo_ctx::Worker& w, const svo_ctx::Job& job) {
-    if (w.err != SVO_OK) return;                 // a failed group drops the rest of its queue
+    if (w.err != SVO_OK || w.ctx_failed->load()) return;   // after a failure (any group) the queues are dropped
     const int rc = grp_new_images(w.g, job.left.data(), job.right.data(), job.stride, job.ts.data(), job.mem);
     if (rc != SVO_OK) {
         w.err = rc;
         w.msg = svo_last_error();
+        w.ctx_failed->store(true);
     }
 }
 
@@ -1259,7 +1264,7 @@ extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int hei
     for (int g = 0; g < G; g++) {
         const int count = n_sequences / G + (g < n_sequences % G ? 1 : 0);
         auto w = std::make_unique<svo_ctx::Worker>();
-        w->first = first; w->count = count;
+        w->first = first; w->count = count; w->ctx_failed = &c->failed;
         const int rc = grp_create(cam, width, height, count, device, &w->g);
         if (rc) {
             for (auto& o : c->workers) grp_destroy(o->g);
@@ -1302,6 +1307,10 @@ extern "C" int svo_ctx_get_groups(svo_ctx* c, int* n_groups) {
 extern "C" int svo_submit_images(svo_ctx* c, const uint8_t* const* left, const uint8_t* const* right,
                                  int stride, const float* time_stamps, int mem) {
     if (!c || !left || !right || !time_stamps) return svo_set_error(SVO_ERR_INVALID, "svo_submit_images: bad arguments");
+    if (c->failed.load()) {                      // nothing is queued on any group once one of them has failed
+        const int rc = ctx_drain(c);             // (the first call after the failure reports its cause)
+        return rc ? rc : svo_set_error(SVO_ERR_INVALID, "svo_submit_images: an earlier frame of this ctx failed; create a new ctx");
+    }
     for (auto& wp : c->workers) {
         svo_ctx::Worker& w = *wp;
         svo_ctx::Job job;

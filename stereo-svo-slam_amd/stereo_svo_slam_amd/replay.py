@@ -253,10 +253,12 @@ def error_report(test_rows, reference_rows):
 class Replay:
     """process_image loop: only the time inside new_image is accumulated (slam_app.cpp:186-190)."""
 
-    def __init__(self, settings, device=0, time_trace=False, exact=False):
+    def __init__(self, settings, device=0, time_trace=False, fast=False):
+        """fast=False keeps the library default: the reference-order Gauss-Newton (bit-exact traces)."""
         self.settings = settings
         self.slam = StereoSlam(settings, device=device)
-        self.slam.set_exact_pinv(exact)
+        if fast:
+            self.slam.set_fast_solver(True)
         self.cumulative = []
         self._t = 0.0
         self.time_trace = time_trace
@@ -294,7 +296,9 @@ def main(argv=None):
     ap.add_argument("--euroc", help="EuRoC mav0/ directory (cam0, cam1): EurocInput conventions")
     ap.add_argument("--sbs", help="'frames/%%06d.png' side-by-side frames: VideoInput conventions")
     ap.add_argument("--time-trace", action="store_true", help="print '<stage> took: X ms' per frame (reference names)")
-    ap.add_argument("--exact", action="store_true", help="reference-order mode of the Gauss-Newton kernels")
+    ap.add_argument("--fast", action="store_true",
+                    help="svo_ctx_set_fast_solver(1): tree sums + LDL^T instead of the default reference-order Gauss-Newton")
+    ap.add_argument("--exact", action="store_true", help="no-op (the reference-order mode is the default)")
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--rate", type=float, default=20.0, help="frames per second of the time stamps")
@@ -327,7 +331,7 @@ def main(argv=None):
         frames = ((*_load_pair(args.pairs, k), k / args.rate) for k in range(args.frames))
     else:
         ap.error("give --synthetic, or --settings with --euroc / --sbs / --pairs (or $SVO_DATA)")
-    rp = Replay(settings, args.device, args.time_trace, args.exact)
+    rp = Replay(settings, args.device, args.time_trace, args.fast)
     for left, right, t in frames:
         rp.feed(left, right, t)
     rows = rp.rows()

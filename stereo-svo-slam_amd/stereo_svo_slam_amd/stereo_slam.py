@@ -93,7 +93,9 @@ class StereoSlamBatch:
         self.set_fast_solver(not on)
 
     def enable_timing(self, on=True):
-        _check(lib().svo_ctx_enable_timing(self._ctx, int(on)))
+        self._timing = bool(on)
+        if self._ctx:                      # (StereoSlam creates its ctx with the first image)
+            _check(lib().svo_ctx_enable_timing(self._ctx, int(on)))
 
     def new_images(self, lefts, rights, time_stamps):
         """lefts/rights: per sequence a uint8 [H, W] numpy array (host) or torch CUDA tensor; None for
@@ -242,4 +244,6 @@ class StereoSlam(StereoSlamBatch):
             super().__init__(cam, w, h, 1, device)
             if getattr(self, "_fast", False):
                 self.set_fast_solver(True)
+            if getattr(self, "_timing", False):
+                self.enable_timing(True)
         self.new_images([left], [right], [time_stamp])

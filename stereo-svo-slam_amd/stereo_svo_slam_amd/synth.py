@@ -84,6 +84,27 @@ def trajectory(n_frames, seed=0, scale=1.0):
     return p.astype(np.float32)
 
 
+def loop_trajectory(n_frames, seed=0, scale=1.0):
+    """Closed 6-DoF camera path of n_frames poses: every component is a sum of sinusoids whose periods
+    divide n_frames, so pose[n_frames] == pose[0] and the frames can be played round and round, from any
+    starting frame, always forward. Sideways / forward drift of about +-0.6 m, yaw of about +-0.5 rad
+    and smaller pitch / roll terms: at 192 frames per lap <= ~4 cm and <= ~1.1 deg per frame (a brisk
+    hand-held / MAV motion), enough image motion that the reference's keyframe rule
+    (src/lib/keyframe_manager.cpp:47-74: fewer than 66 % of the grid cells hold a visible point) fires
+    every few tens of frames, as it does on the reference's own sequences."""
+    rng = np.random.RandomState(3000 + seed)
+    ph = rng.uniform(0, 2 * math.pi, 12)
+    a = 2 * math.pi * np.arange(n_frames, dtype=np.float64) / n_frames
+    x = 0.55 * np.sin(a + ph[0]) + 0.10 * np.sin(3 * a + ph[1])
+    y = 0.10 * np.sin(2 * a + ph[2]) + 0.04 * np.sin(5 * a + ph[3])
+    z = 0.45 * np.sin(a + ph[0] + 1.3) + 0.10 * np.sin(2 * a + ph[4])
+    rx = 0.10 * np.sin(3 * a + ph[5]) + 0.03 * np.sin(7 * a + ph[6])
+    ry = 0.42 * np.sin(2 * a + ph[7]) + 0.10 * np.sin(3 * a + ph[8])
+    rz = 0.05 * np.sin(4 * a + ph[9]) + 0.02 * np.sin(6 * a + ph[10])
+    p = np.stack([x, y, z, rx, ry, rz], 1) * scale
+    return p.astype(np.float32)
+
+
 def _texture(rng, size=1024):
     t = np.full((size, size), 128.0, np.float32)
     for s, a in ((128, 28.0), (64, 26.0), (32, 24.0), (16, 20.0), (8, 14.0), (4, 8.0)):

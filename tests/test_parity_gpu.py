@@ -154,8 +154,9 @@ def _sia_inputs(sc, frame):
 @pytest.mark.parametrize("exact", [False, True])
 def test_sia_first_gradient_matches(H, config, seed, exact):
     """H = sum J^T J, b and the GN step of the first get_gradient on the coarsest level.
-    Reference-order mode accumulates row by row like the reference (pose_estimator.cpp:399-403,
-    :472-477); the default mode sums J^T (sum g g^T) J per keypoint in a tree."""
+    exact=True is the product default: row-by-row accumulation like the reference
+    (pose_estimator.cpp:399-403, :472-477); exact=False is the opt-in fast solver
+    (svo_set_fast_solver), which sums J^T (sum g g^T) J per keypoint in a tree."""
     sc = util.scenario(config, 3, seed, 1)
     cfg = sc["cfg"]
     prev, cur, k2, k3, fl = _sia_inputs(sc, 1)
@@ -281,8 +282,8 @@ def test_reproj_gn_matches(H, config, seed, exact):
         assert int(tr["n_gradient"]) == tref["n_gradient"], (tr, tref)
         assert int(tr["n_cost"]) == tref["n_cost"], (tr, tref)
         assert int(tr["n_accepted"]) == tref["n_accepted"]
-    # (default mode: the LDL^T solve in double is not the reference's float SVD inverse, whose error in
-    # the weak directions of J^T J is large; the steps differ, the minimum within 1e-4 does not)
+    # (fast solver, exact=False: the LDL^T solve in double is not the reference's float SVD inverse, whose
+    # error in the weak directions of J^T J is large; the steps differ, the minimum within 1e-4 does not)
     assert tr["initial_cost"] == tref["initial_cost"]            # same pose, sequential sum: same bits
     assert abs(float(cost.cpu()) - cref) < (1e-5 if exact else 1e-3)
 

@@ -198,13 +198,14 @@ def test_time_trace_uses_the_reference_stage_names():
 @pytest.mark.gpu
 def test_replay_euroc_layout_equals_the_oracle(tmp_path, monkeypatch):
     """$SVO_DATA pointing at a EuRoC mav0/ directory: the harness reads it with the reference's
-    conventions and the CSV it writes is the oracle's trajectory (reference-order mode)."""
+    conventions and the CSV it writes is the oracle's trajectory. No solver flag: the replay default
+    is the library default, the reference-order Gauss-Newton."""
     import oracle_py as O
     import util
     mav, y, L, R = _write_euroc(tmp_path)
     monkeypatch.setenv("SVO_DATA", mav)
     out = tmp_path / "traj.csv"
-    replay.main(["--settings", y, "--frames", "3", "--exact", "-t", str(out)])
+    replay.main(["--settings", y, "--frames", "3", "-t", str(out)])
     rows = np.loadtxt(str(out), delimiter=",")
     cfg = dict(synth.CONFIGS["tiny"])
     ref = O.Slam(util.oracle_camera(cfg))
@@ -212,3 +213,27 @@ def test_replay_euroc_layout_equals_the_oracle(tmp_path, monkeypatch):
         ref.new_image(L[k].numpy(), R[k].numpy(), float(np.float32(0.05 * k)))
         exp = np.concatenate([ref.pose()[:3], replay.csv_angles(ref.pose())])
         assert np.allclose(rows[k, 1:], exp, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_replay_default_trace_is_the_oracles_and_time_trace_runs(capsys):
+    """Replay() without flags tracks with the reference-order solver: pose and every GN trace equal
+    the oracle's frame by frame. time_trace=True (the ctx does not exist before the first image)
+    prints the reference's stage names from the first tracked frame on."""
+    import oracle_py as O
+    import util
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", 5, 4, device="cpu")
+    ref = O.Slam(util.oracle_camera(cfg))
+    rp = replay.Replay(cfg, time_trace=True)
+    for k in range(5):
+        ref.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        rp.feed(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        assert np.array_equal(rp.slam.get_frame().pose, ref.pose()), k
+        if k:
+            a, b = rp.slam.stats(), ref.stats()
+            for lv in range(cfg["min_pyramid_level_pose_estimation"], cfg["max_pyramid_levels"]):
+                x, y = a.sia_trace[lv], b.sia_trace[lv]
+                assert (x.n_gradient, x.n_cost, x.n_accepted) == (y.n_gradient, y.n_cost, y.n_accepted), (k, lv)
+            assert sum(a.stage_ms) > 0
+    out = capsys.readouterr().out
+    assert out.count("Stereo SLAM took:") == 5 and "estimator took:" in out

@@ -51,12 +51,12 @@ def _same_trace(a, b, cfg):
                (y.n_gradient, y.n_cost, y.n_accepted, y.exit_small) for x, y in pairs)
 
 
-def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False, tol=None,
+def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=True, tol=None,
          render_device="cpu"):
-    """Both trackers frame by frame. exact (the default, reference-order mode): every GN trace must
-    equal the oracle's and the pose is the oracle's bit for bit; exact=False (svo_ctx_set_fast_solver):
-    pose within 1e-4. Returns the fraction of tracked frames whose GN traces equal the
-    oracle's as the third value."""
+    """Both trackers frame by frame. exact=True (the default here and of the product: the
+    reference-order mode): every GN trace must equal the oracle's and the pose is the oracle's bit for
+    bit; exact=False (svo_ctx_set_fast_solver): pose within 1e-4. Returns the fraction of
+    tracked frames whose GN traces equal the oracle's as the third value."""
     if tol is None:
         tol = 0.0 if exact else 1e-4
     cfg, L, R, poses, ts = synth.make_sequence(config, n_frames, seed, device=render_device,
@@ -66,7 +66,8 @@ def _run(config, n_frames, seed, on_device=False, motion_scale=1.0, exact=False,
     cam = util.oracle_camera(cfg)
     ref = O.Slam(cam)
     gpu = StereoSlam(cfg, cfg["width"], cfg["height"])
-    gpu.set_exact_pinv(exact)
+    if not exact:                      # (exact: nothing is set — the product default is under test)
+        gpu.set_fast_solver(True)
     n_kf = 0
     same = 0
     for k in range(n_frames):
@@ -143,8 +144,9 @@ def test_sequence_matches_oracle(config, n_frames, seed, exact):
 
 
 def test_sequence_with_keyframe_creation():
-    """Fast motion so that keyframe_needed fires inside the sequence."""
-    gpu, ref, _ = _run("tiny", 30, 1, motion_scale=4.0)
+    """Fast motion so that keyframe_needed fires inside the sequence (product default solver)."""
+    gpu, ref, same = _run("tiny", 30, 1, motion_scale=4.0)
+    assert same == 1.0
     assert ref.num_keyframes() >= 2
 
 
@@ -223,6 +225,39 @@ def test_batched_launch_shapes_equal_single(monkeypatch):
     batch.close()
 
 
+def test_batched_c2_shape_in_groups_equals_the_oracle(monkeypatch):
+    """The launch shape the headline number runs (sia_gn_kernel<1,2>: one wave per sequence, records and
+    image taps from L2; several sequence groups on their own streams; frames used in place, queued
+    with svo_submit_images) at the C2 size, pinned to the oracle DIRECTLY: 66 `euroc` sequences in 3
+    groups, 5 frames; every sequence's pose, keypoints, flags, counters and trajectory equal the
+    oracle's bit for bit."""
+    n_seq, n_frames = 66, 5
+    monkeypatch.setenv("SVO_GROUPS", "3")
+    rendered = [synth.make_sequence_gpu("euroc", n_frames, 100 + s, motion_scale=1.5) for s in range(n_seq)]
+    cfg = rendered[0][0]
+    batch = StereoSlamBatch(cfg, cfg["width"], cfg["height"], n_seq)
+    assert batch.groups() == 3
+    torch.cuda.synchronize()
+    packs = [batch.pack_images([r[1][k] for r in rendered], [r[2][k] for r in rendered],
+                               [float(r[4][k]) for r in rendered], borrow=True) for k in range(n_frames)]
+    for pk in packs:
+        batch.submit_packed(pk)
+    batch.wait()
+    cam = util.oracle_camera(cfg)
+    for i, r in enumerate(rendered):
+        ref = O.Slam(cam)
+        L, R = r[1].cpu().numpy(), r[2].cpu().numpy()
+        traj = []
+        for k in range(n_frames):
+            ref.new_image(L[k], R[k], float(r[4][k]))
+            traj.append(ref.pose().copy())
+        ok2, ok3, oinfo = ref.keypoints()
+        _compare_frame(f"euroc batch seq {i}", batch.get_frame(i), ok2, ok3, oinfo, ref.pose(), tol=0.0)
+        assert np.array_equal(batch.get_trajectory(i), np.array(traj)), i
+        assert _same_trace(batch.stats(i), ref.stats(), cfg), i
+    batch.close()
+
+
 def test_groups_and_pipelined_submit_equal_lockstep(monkeypatch):
     """Sequence groups (own stream + host thread each) and svo_submit_images / svo_wait give
     the results of the single-group, call-per-frame form: 5 sequences as 1 group vs 2 groups
@@ -257,6 +292,35 @@ def test_groups_and_pipelined_submit_equal_lockstep(monkeypatch):
         assert np.array_equal(a.info, b.info)
         assert np.array_equal(one.get_trajectory(i), two.get_trajectory(i))
         assert one.num_keyframes(i) == two.num_keyframes(i)
+
+
+def test_failure_in_one_group_latches_the_ctx(monkeypatch):
+    """A frame that fails in one sequence group (here: a sequence handed only one of its two images)
+    fails the ctx: the wait reports the cause, nothing more is queued on ANY group afterwards, so the
+    healthy group's sequences do not run ahead on later submits."""
+    from stereo_svo_slam_amd.hip_lib import SvoError
+    seqs = [synth.make_sequence("tiny", 3, 30 + s, device="cpu") for s in range(4)]
+    cfg = seqs[0][0]
+    monkeypatch.setenv("SVO_GROUPS", "2")
+    ctx = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 4)
+    assert ctx.groups() == 2
+    dl = [[s[1][k].cuda() for s in seqs] for k in range(3)]
+    dr = [[s[2][k].cuda() for s in seqs] for k in range(3)]
+    torch.cuda.synchronize()
+    ctx.new_images_packed(ctx.pack_images(dl[0], dr[0], [0.0] * 4))
+    bad = ctx.pack_images(dl[1], dr[1], [0.05] * 4)
+    bad[1][3] = None                                   # sequence 3 (second group): right image missing
+    ctx.submit_packed(bad)
+    with pytest.raises(SvoError, match="only one image"):
+        ctx.wait()
+    frames_after_failure = ctx.totals().frames           # group 0 may have run frame 1, group 1 has not
+    assert frames_after_failure in (4, 6)
+    with pytest.raises(SvoError, match="earlier frame of this ctx failed"):
+        ctx.submit_packed(ctx.pack_images(dl[2], dr[2], [0.1] * 4))
+    with pytest.raises(SvoError, match="earlier frame of this ctx failed"):
+        ctx.new_images_packed(ctx.pack_images(dl[2], dr[2], [0.1] * 4))
+    assert ctx.totals().frames == frames_after_failure
+    ctx.close()
 
 
 def test_update_pose_matches_oracle():
