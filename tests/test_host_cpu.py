@@ -203,6 +203,36 @@ def test_bench_algorithmic_bytes_follow_design_section_5():
     assert ab["reproj_gn"] == 24 * n and ab["filter_update"] == 64 * n
 
 
+def test_bench_loop_plan_and_group_sample():
+    """bench.py's workload plan: ctx sequence s plays loop s % n_loops from its own entry frame, always
+    forward; sequences sharing a loop never show the same frame at the same step; the parity sample
+    takes two sequences of every sequence group, the first G entries covering all groups."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    plan = bench.loop_plan(2048, 128, 192)
+    assert len(plan) == 2048 and plan[0] == (0, 0) and plan[128] == (0, 12) and plan[2047] == (127, 180)
+    for k in (0, 5, 191, 400):
+        frames = {}
+        for s, (loop, off) in enumerate(plan):
+            f = bench.frame_index(k, 192, off)
+            assert (loop, f) not in frames, (k, s, frames.get((loop, f)))
+            frames[(loop, f)] = s
+    assert [bench.frame_index(k, 192, 190) for k in range(4)] == [190, 191, 0, 1]
+    seqs, groups = bench.group_sample(2048, 8)
+    assert seqs[:8] == [0, 256, 512, 768, 1024, 1280, 1536, 1792] and groups[:8] == list(range(8))
+    assert seqs[8:] == [s + 1 for s in seqs[:8]] and len(set(groups)) == 8
+    seqs, groups = bench.group_sample(10, 3)          # groups of 4, 3, 3
+    assert seqs == [0, 4, 7, 1, 5, 8] and groups == [0, 1, 2, 0, 1, 2]
+
+
+def test_loop_trajectory_is_closed_and_smooth():
+    p = synth.loop_trajectory(192, 3, 0.75)
+    assert p.shape == (192, 6)
+    step = np.abs(np.diff(np.vstack([p, p[:1]]), axis=0))          # includes the wrap-around step
+    assert step[:, :3].max() < 0.03 and np.degrees(step[:, 3:].max()) < 2.0
+    assert np.allclose(step[-1], np.abs(p[0] - p[-1]))
+
+
 def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path):
     """profiles/r02_pmc.json (read by bench.py for roofline.binding_roof) is what
     tools/make_pmc_json.py derives from the committed counter and kernel-stats CSVs."""
