@@ -87,14 +87,15 @@ __device__ inline void lds_pairs(uint32_t a, int (&r)[N]) {
     for (int u = 0; u < N; u++) r[u] |= hi[u] << 16;
 }
 
-// exact 64-bit sum of per-thread int32 partials over the workgroup
-// (DPP row adds per wave, waves combined through LDS), same value in every thread
+// exact sum of per-thread int32 partials over the workgroup as a double (an integer below 2^53:
+// exact; (float) of it rounds once, like (float) of the 64-bit integer sum OpenCV's scalar path forms).
+// DPP adds per wave, waves combined through LDS; same value in every thread
 template <int NV>
-__device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], long long (*s_part)[4]) {
+__device__ inline void klt_block_sum(const int (&v)[NV], double (&out)[NV], double (*s_part)[4]) {
     const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        const long long w = wave_sum_i32_to_i64(v[k]);
+        const double w = wave_sum_i32_to_f64(v[k]);
         if (KLT_WAVES == 1) out[k] = w;
         else if ((threadIdx.x & 63) == 0) s_part[wave][k] = w;
     }
@@ -102,7 +103,7 @@ __device__ inline void klt_block_sum(const int (&v)[NV], long long (&out)[NV], l
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        long long t = 0;
+        double t = 0;
 #pragma unroll
         for (int w = 0; w < KLT_WAVES; w++) t += s_part[w][k];
         out[k] = t;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     __shared__ __attribute__((aligned(16))) uint8_t s_I[KLT_RROWS * KLT_RS];
     __shared__ int s_d[(KLT_DW + 1) * KLT_DW];    // packed (dx, dy) int16; + one slack row
     __shared__ __attribute__((aligned(16))) uint8_t s_J[KLT_TJROWS * KLT_TJS];
-    __shared__ long long s_part[KLT_WAVES][4];
+    __shared__ double s_part[KLT_WAVES][4];
 
     // the keyframe record is wave-uniform: its fields are read where they are used. (A local copy of
     // the struct lands in scratch memory — 216 B per lane written and read back per keypoint, 0.7 GB
@@ -323,14 +324,13 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 dxp = dxp1; dyp = dyp1;
             }
         }
-        long long sA[3];
+        double sA[3];
         {
             const int pa[3] = {a11, a12, a22};
             klt_block_sum<3>(pa, sA, s_part);
         }
-        const long long iA11 = sA[0], iA12 = sA[1], iA22 = sA[2];
-        const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE,
-                    A22 = (float)iA22 * FLT_SCALE;
+        const float A11 = (float)sA[0] * FLT_SCALE, A12 = (float)sA[1] * FLT_SCALE,
+                    A22 = (float)sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                              (2 * win * win);
@@ -381,13 +381,12 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                     b2 = dot2(diff, as_v2s(tIy[k]), b2);
                 }
             }
-            long long sB[2];
+            double sB[2];
             {
                 const int pb[2] = {b1, b2};
                 klt_block_sum<2>(pb, sB, s_part);
             }
-            const long long ib1 = sB[0], ib2 = sB[1];
-            const float fb1 = (float)ib1 * FLT_SCALE, fb2 = (float)ib2 * FLT_SCALE;
+            const float fb1 = (float)sB[0] * FLT_SCALE, fb2 = (float)sB[1] * FLT_SCALE;
             const float dx = (float)((A12 * fb2 - A22 * fb1) * D);
             const float dy = (float)((A12 * fb1 - A11 * fb2) * D);
             nextx += dx; nexty += dy;
@@ -421,12 +420,8 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                     if (y0 + 2 * k + 1 < win) e += abs((int)diff.y);
                 }
             }
-            long long sE[1];
-            {
-                const int pe[1] = {e};
-                klt_block_sum<1>(pe, sE, s_part);   // < 2^24: the float sum of |diff| is exact in any order
-            }
-            const float errval = (float)(int)sE[0];
+            // < 2^24: the float sum of |diff| is exact in any order
+            const float errval = (float)(KLT_WAVES == 1 ? wave_sum_bcast_i(e) : (int)[&] { double sE[1]; const int pe[1] = {e}; klt_block_sum<1>(pe, sE, s_part); return sE[0]; }());
             err = errval * 1.f / (32 * win * win);
         }
     }

@@ -77,7 +77,11 @@ __device__ inline float patch_sum_lds(const LevelImg<BIG>& im, float cx, float c
 #ifndef SVO_SIA_STG
 #define SVO_SIA_STG 64
 #endif
-constexpr int SIA_STG = SVO_SIA_STG;    // keypoints whose rows are staged at a time in reference-order mode
+constexpr int SIA_STG = SVO_SIA_STG;
+#ifndef SVO_SIA_ACC_U
+#define SVO_SIA_ACC_U 4
+#endif
+constexpr int SIA_ACC_U = SVO_SIA_ACC_U;   // keypoints per trip of the ordered accumulation (their LDS reads are in flight together)    // keypoints whose rows are staged at a time in reference-order mode
 enum { KF_PX = 0, KF_PY, KF_PZ, KF_QX, KF_QY, KF_GXX, KF_GXY, KF_GYY, KF_ACT, KF_COUNT };
 enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
 struct SiaLds {
@@ -495,21 +499,22 @@ struct Sia {
                             eacc += a3.x * b3.x; eacc += a3.y * b3.y; eacc += a3.z * b3.z; eacc += a3.w * b3.w;
                         }
 #else
-                        for (int j = 0; j < m; j += 4) {
-                            v4f ra[4][4], rb[4][4];
+                        for (int j = 0; j < m; j += SIA_ACC_U) {
+                            v4f ra[SIA_ACC_U][4], rb[SIA_ACC_U][4];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < SIA_ACC_U; u++) {
                                 const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + (j + u) * KS);
                                 const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + (j + u) * KS);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) { ra[u][e] = qa[e]; rb[u][e] = qb[e]; }
                             }
+                            // products two at a time (v_pk_mul_f32: the same IEEE products), the adds in storage order
 #pragma unroll
-                            for (int u = 0; u < 4; u++)
+                            for (int u = 0; u < SIA_ACC_U; u++)
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
-                                    eacc += ra[u][e].x * rb[u][e].x; eacc += ra[u][e].y * rb[u][e].y;
-                                    eacc += ra[u][e].z * rb[u][e].z; eacc += ra[u][e].w * rb[u][e].w;
+                                    const v2f p0 = ra[u][e].lo * rb[u][e].lo, p1 = ra[u][e].hi * rb[u][e].hi;
+                                    eacc += p0.x; eacc += p0.y; eacc += p1.x; eacc += p1.y;
                                 }
                         }
 #endif

@@ -112,6 +112,23 @@ __device__ inline int wave_sum_dpp_i(int v) {
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
+// sum over the 64 lanes with the wave-wide DPP forms of gfx9 (row_bcast:15 / row_bcast:31 carry a
+// row's last lane into the next rows): six fused v_add_u32_dpp and one v_readlane (wave_sum_dpp_i:
+// four adds, four readlanes, three scalar adds). Integer adds: any order gives the same bits.
+__device__ inline int wave_sum_bcast_i(int v) {
+    v = row16_sum_dpp_i(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// exact sum of per-lane int32 partials (|v| < 2^31) as a double (|sum| < 2^37 is an integer a double
+// holds exactly): low 16 bits and the signed high part are reduced separately in int32. (float) of
+// the result rounds the exact integer once, like (float) of the 64-bit integer sum.
+__device__ inline double wave_sum_i32_to_f64(int v) {
+    const int lo = wave_sum_bcast_i(v & 0xFFFF);
+    const int hi = wave_sum_bcast_i(v >> 16);
+    return (double)hi * 65536.0 + (double)lo;
+}
 // exact 64-bit sum of per-lane int32 partials (|v| < 2^31): low 16 bits and the
 // signed high part are reduced separately in int32 and recombined
 __device__ inline long long wave_sum_i32_to_i64(int v) {
@@ -122,6 +139,7 @@ __device__ inline long long wave_sum_i32_to_i64(int v) {
 
 // ------------------------------------------------- reference-order sums
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // sequential sum of buf[0..n) continuing from s. buf is in LDS, zero padded to a multiple of 128
 // floats (adding the zeros is exact): every block of 128 is 32 ds_read_b128 issued back to back

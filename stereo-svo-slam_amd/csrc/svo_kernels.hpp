@@ -24,7 +24,9 @@ struct PyrArgs {
 };
 // both pyramids of `batch` left images of w x h in one launch; right_blocks: extra workgroups copy
 // src_right -> dst_right (ingest of device-resident frames)
-void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, hipStream_t stream);
+// stream_ok: pyr_stream_ok() holds for every argument block of the launch (the row-streaming kernel; else the tile kernel)
+void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, bool stream_ok, hipStream_t stream);
+bool pyr_stream_ok(const PyrArgs& host_args);
 
 // ------------------------------------------------- sparse image alignment
 struct SiaArgs {
