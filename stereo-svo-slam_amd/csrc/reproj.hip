@@ -266,7 +266,9 @@ void launch_project(const float* pose, const svo_kp3d* kps3d, int n, const svo_c
 // 24 B each). One wave per sequence up to 128 keypoints, four beyond. Returns false when the
 // keypoints do not fit LDS (more than ~5000).
 bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t stream) {
-    const int T = n_bound <= 128 ? 64 : 256;
+    // a batch of sequences: one wave each up to 256 keypoints (four staging steps): the four-wave shape took
+    // 2.0 against 0.8 ms per launch in the round-3 profile, for every sequence of a launch whose largest set passed 128
+    const int T = n_bound <= (batch >= 32 ? 256 : 128) ? 64 : 256;
     const int cap = (std::max(n_bound, 1) + T - 1) / T * T;          // whole staging steps
     const size_t lds = (size_t)cap * 6 * sizeof(float);
     if (lds > 120 * 1024) return false;
@@ -277,7 +279,7 @@ bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     });
-    if (n_bound <= 128)
+    if (T == 64)
         hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), lds, stream, d_args, cap);
     else
         hipLaunchKernelGGL(reproj_gn_kernel<4>, dim3(batch), dim3(256), lds, stream, d_args, cap);

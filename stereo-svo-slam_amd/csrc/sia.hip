@@ -220,6 +220,7 @@ struct Sia {
 
     const SiaArgs& a;
     int n, cap;
+    int npad;                        // n rounded up to whole passes of the workgroup: the keypoint loops of THIS sequence
     uint8_t* dyn;
     SiaLds lay;
     LevelImg<BIG> cur;
@@ -229,7 +230,7 @@ struct Sia {
     int par = 0;
 
     __device__ Sia(const SiaArgs& a_, int n_, int cap_, uint8_t* dyn_, const SiaLds& lay_)
-        : a(a_), n(n_), cap(cap_), dyn(dyn_), lay(lay_) {}
+        : a(a_), n(n_), cap(cap_), npad(min(cap_, (n_ + T - 1) / T * T)), dyn(dyn_), lay(lay_) {}
 
     __device__ inline float kpf_ld(int f, int i) const {
         if constexpr (BIG) return G(a.kp_ws)[(size_t)f * cap + i];
@@ -288,7 +289,7 @@ struct Sia {
         float* buf = reinterpret_cast<float*>(dyn + lay.tbuf) + par * cap;
         par ^= 1;
         float total = 0;
-        for (int i = threadIdx.x; i < cap; i += T) {
+        for (int i = threadIdx.x; i < npad; i += T) {     // (passes beyond the sequence's own keypoints would add exact zeros)
             float v = 0;
             if (kpf_ld(KF_ACT, i) != 0.f) {
                 const svo_kp2d q = project_point(pm.Rd, pm.t, camd, svo_kp3d{kpf_ld(KF_PX, i), kpf_ld(KF_PY, i), kpf_ld(KF_PZ, i)});
@@ -358,7 +359,7 @@ struct Sia {
         constexpr int PS = SIA_STG * KS + 4;         // plane stride: the 7 planes start on different banks
         float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index slot*KS + px
 
-        for (int i0 = 0; i0 < cap; i0 += T) {
+        for (int i0 = 0; i0 < npad; i0 += T) {
             const int i = i0 + tid;
             float J[12];
 #pragma unroll
@@ -781,7 +782,10 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     const bool batched = batch >= 32;
     int waves = nb <= 64 ? 1 : nb <= 128 ? 2 : 4;
     int mode = 0;
-    if (batched) { mode = 2; waves = nb <= 128 ? 1 : nb <= 256 ? 2 : 4; }
+    // (the bound is the LARGEST keypoint set of the launch; a sequence only walks its own keypoints. One wave up to
+    // 192: with keyframes at the reference's rate the sets reach ~160, and the two-wave shape costs every sequence
+    // of the launch a second wave — 5.7 against 4.8 ms per launch in the round-3 profile)
+    if (batched) { mode = 2; waves = nb <= 192 ? 1 : nb <= 384 ? 2 : 4; }
     // (experiments: SVO_SIA_MODE = 0 / 1 / 2 and SVO_SIA_WAVES = 1 / 2 / 4 force the shape of batched launches)
     static const int env_mode = getenv("SVO_SIA_MODE") ? atoi(getenv("SVO_SIA_MODE")) : -1;
     static const int env_waves = getenv("SVO_SIA_WAVES") ? atoi(getenv("SVO_SIA_WAVES")) : 0;

@@ -304,6 +304,7 @@ struct svo_group {
     size_t set_bytes = 0;
     std::vector<void*> allocs;   // everything to free
     std::vector<uint8_t*> kf_slabs;   // free per-keyframe keypoint storage (allocated in chunks)
+    std::vector<uint8_t*> set_slabs;  // free image-set storage (allocated in chunks)
     svo_totals totals;
     HostPool* pool = nullptr;
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
@@ -324,10 +325,20 @@ int dev_alloc(svo_group* c, T** p, size_t count) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int new_image_set(svo_group* c, ImageSet** out) {
-    ImageSet* s = new ImageSet();
+// Image-set storage comes from slabs allocated in chunks: one hipMalloc (a device-wide
+// synchronising call) per chunk of sets, not per set — every keyframe keeps its set for good, so a
+// long run asks for one per keyframe.
+int grow_set_slabs(svo_group* c, int count) {
+    uint8_t* base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), c->set_bytes * (size_t)count));
+    c->allocs.push_back(base);
+    for (int i = count - 1; i >= 0; i--) c->set_slabs.push_back(base + c->set_bytes * (size_t)i);
+    return SVO_OK;
+}
+
+// layout of one image set (byte offsets into its slab); fills c->set_bytes
+void image_set_layout(svo_group* c, ImageSet* s, size_t* offs_left, size_t* offs_lk, size_t* off_right) {
     size_t off = 0;
-    size_t offs_left[SVO_MAX_PYRAMID_LEVELS], offs_lk[SVO_LK_LEVELS], off_right;
     int w = c->width, h = c->height;
     for (int l = 0; l < c->cam.max_pyramid_levels; l++) {
         const int stride = (int)align_up((size_t)std::max(w, 1), 64);
@@ -338,7 +349,7 @@ int new_image_set(svo_group* c, ImageSet** out) {
     }
     {
         const int stride = (int)align_up((size_t)c->width, 64);
-        off_right = off;
+        *off_right = off;
         s->right = ImgView{nullptr, c->width, c->height, stride};
         off += align_up((size_t)stride * c->height, 256);
     }
@@ -350,17 +361,25 @@ int new_image_set(svo_group* c, ImageSet** out) {
         s->lk[l] = ImgView{nullptr, w, h, stride};
         off += align_up((size_t)stride * h, 256);
     }
-    void* base = nullptr;
-    HIP_TRY(hipMalloc(&base, off));
-    c->allocs.push_back(base);
-    s->base = reinterpret_cast<uint8_t*>(base);
+    c->set_bytes = off;
+}
+
+int new_image_set(svo_group* c, ImageSet** out) {
+    ImageSet* s = new ImageSet();
+    size_t offs_left[SVO_MAX_PYRAMID_LEVELS], offs_lk[SVO_LK_LEVELS], off_right;
+    image_set_layout(c, s, offs_left, offs_lk, &off_right);
+    if (c->set_slabs.empty()) {
+        const int rc = grow_set_slabs(c, std::max(c->B, 16));
+        if (rc) { delete s; return rc; }
+    }
+    s->base = c->set_slabs.back();
+    c->set_slabs.pop_back();
     for (int l = 0; l < c->cam.max_pyramid_levels; l++) s->left[l].data = s->base + offs_left[l];
     s->right.data = s->base + off_right;
     s->lk[0] = s->left[0];
     s->own_left0 = s->left[0];
     s->own_right = s->right;
     for (int l = 1; l < c->n_lk; l++) s->lk[l].data = s->base + offs_lk[l];
-    c->set_bytes = off;
     *out = s;
     return SVO_OK;
 }
@@ -576,6 +595,12 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     for (int i = 0; i < 10; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
     c->seqs.resize(B);
+    {   // the first four image sets of every sequence: one allocation
+        ImageSet probe;
+        size_t ol[SVO_MAX_PYRAMID_LEVELS], olk[SVO_LK_LEVELS], orr;
+        image_set_layout(c, &probe, ol, olk, &orr);
+        if ((rc = grow_set_slabs(c, 4 * B))) return rc;
+    }
     if (B >= 16) {
         // SVO_HOST_THREADS: host threads per group for the deferred pose filter
         // (default 1 = off: at the measured kernel times the filter hides behind the GPU work)
