@@ -30,8 +30,19 @@ constexpr int KLT_MARGIN = 6;
 constexpr int KLT_DW = KLT_MAX_WIN + 1;                 // derivative / tap grid edge
 constexpr int KLT_RS = 44;                              // row stride of the reference tile: (w+3) + 3 alignment slack, /4
 constexpr int KLT_RROWS = KLT_MAX_WIN + 3;              // also >= 1 + rows covered by the row groups + 1
-constexpr int KLT_TJS = 52;                             // row stride of the search tile: (w+1) + 2*margin + 3, /4
+constexpr int KLT_TJS = 52;                             // columns of the search tile: (w+1) + 2*margin + 3, /4 (<= 2 * KLT_J2S)
 constexpr int KLT_TJROWS = KLT_DW + 2 * KLT_MARGIN + 2;  // + slack: idle rows of the last row group are read, not used
+// The search tile is kept as 16-bit values (pixel << 7) in TWO copies, the second shifted by one pixel:
+// the bilinear pair (p[x], p[x+1]) of any column x is then ONE aligned ds_read_b32 (copy x & 1, dword
+// x >> 1) that already is the int16 pair v_dot2 wants — no byte loads, no packing in the iteration.
+// (Unaligned ds_read_b32 stall the LDS pipeline: SQ_LDS_UNALIGNED_STALL.) The << 7 turns the
+// (sum + 2^8) >> 9 of the fixed-point interpolation into a >> 16: the two results of a row pair are
+// the high halves of two dwords, one v_perm_b32. Row stride 27 dwords (16 rows = 48 banks on) and the
+// second copy 32 banks away from the first: the 32 columns x 2 row groups of a window read hit 64
+// different banks.
+constexpr int KLT_J2S = 27;                             // dwords per tile row of one copy (54 pixels >= KLT_TJS)
+constexpr int KLT_J2COPY = ((KLT_TJROWS * KLT_J2S + 63) / 64) * 64 + 32;   // dwords between the two copies
+static_assert(KLT_TJS <= 2 * KLT_J2S, "search tile row");
 #ifndef SVO_KLT_THREADS
 #define SVO_KLT_THREADS 64          // 128: two waves per keypoint (4 row groups of 8 rows)
 #endif
@@ -87,17 +98,40 @@ __device__ inline void lds_pairs(uint32_t a, int (&r)[N]) {
     for (int u = 0; u < N; u++) r[u] |= hi[u] << 16;
 }
 
-// exact sum of per-thread int32 partials over the workgroup as a double (an integer below 2^53:
-// exact; (float) of it rounds once, like (float) of the 64-bit integer sum OpenCV's scalar path forms).
-// DPP adds per wave, waves combined through LDS; same value in every thread
+// exact sums of NV per-thread int32 partials over the wavefront as doubles (integers below 2^53:
+// exact; (float) of one rounds once, like (float) of the 64-bit integer sum). Each partial is split
+// into its low 16 bits and the signed high part (the 64-lane sum of either fits int32) and the 2 NV
+// reductions run step by step side by side: a DPP add needs two wait states behind the write of its
+// source, which the other chains fill (one chain after the other left an s_nop behind every add).
+template <int CTRL, int N>
+__device__ inline void dpp_add_all(int (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_i<CTRL>(v[k]);
+}
 template <int NV>
-__device__ inline void klt_block_sum(const int (&v)[NV], double (&out)[NV], double (*s_part)[4]) {
+__device__ inline void wave_sums_i32_to_f64(const int (&v)[NV], double (&out)[NV]) {
+    int p[2 * NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) { p[2 * k] = v[k] & 0xFFFF; p[2 * k + 1] = v[k] >> 16; }
+    dpp_add_all<0xB1>(p); dpp_add_all<0x4E>(p); dpp_add_all<0x141>(p); dpp_add_all<0x140>(p);
+#pragma unroll
+    for (int k = 0; k < 2 * NV; k++) p[k] += __builtin_amdgcn_update_dpp(0, p[k], 0x142, 0xA, 0xF, false);   // row_bcast:15
+#pragma unroll
+    for (int k = 0; k < 2 * NV; k++) p[k] += __builtin_amdgcn_update_dpp(0, p[k], 0x143, 0xC, 0xF, false);   // row_bcast:31
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        out[k] = (double)__builtin_amdgcn_readlane(p[2 * k + 1], 63) * 65536.0 + (double)__builtin_amdgcn_readlane(p[2 * k], 63);
+}
+// the same over the workgroup (waves combined through LDS); same value in every thread
+template <int NV>
+__device__ inline void klt_block_sum(const int (&v)[NV], double (&out)[NV], double (*s_part)[8]) {
     const int wave = threadIdx.x >> 6;
+    double w[NV];
+    wave_sums_i32_to_f64<NV>(v, w);
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        const double w = wave_sum_i32_to_f64(v[k]);
-        if (KLT_WAVES == 1) out[k] = w;
-        else if ((threadIdx.x & 63) == 0) s_part[wave][k] = w;
+        if (KLT_WAVES == 1) out[k] = w[k];
+        else if ((threadIdx.x & 63) == 0) s_part[wave][k] = w[k];
     }
     if (KLT_WAVES == 1) return;
     __syncthreads();
@@ -105,7 +139,7 @@ __device__ inline void klt_block_sum(const int (&v)[NV], double (&out)[NV], doub
     for (int k = 0; k < NV; k++) {
         double t = 0;
 #pragma unroll
-        for (int w = 0; w < KLT_WAVES; w++) t += s_part[w][k];
+        for (int ww = 0; ww < KLT_WAVES; ww++) t += s_part[ww][k];
         out[k] = t;
     }
     __syncthreads();
@@ -169,6 +203,60 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
     }
 }
 
+// Search tile: rows [y0, y0+rows) x columns [x0, x0+4*nq) of `im` as (pixel << 7) 16-bit values in
+// two copies, copy 0 from column 0 and copy 1 from column 1 (KLT_J2S dwords per row, KLT_J2COPY
+// dwords apart). Inside the image: one dword per lane, 16 lanes per row (a DPP row: the next
+// dword's first pixel comes from the neighbouring lane); else byte by byte with BORDER_REFLECT_101.
+__device__ inline void stage_tile_j2(uint32_t* tile, const ImgView& im, int x0, int y0, int nq, int rows) {
+    const int tid = threadIdx.x;
+    const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * nq <= im.w && y0 + rows <= im.h &&
+                      (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
+    if (fast) {
+        constexpr int RPP = KLT_THREADS / 16;                        // rows per pass
+        constexpr int NP = (KLT_TJROWS + RPP - 1) / RPP;
+        const int c4 = tid & 15, r0 = tid >> 4;
+        const uint8_t* g = im.g() + M24(y0 + r0, im.stride) + x0 + 4 * min(c4, nq - 1);
+        uint32_t v[NP];
+#pragma unroll
+        for (int u = 0; u < NP; u++)
+            v[u] = (r0 + u * RPP < rows) ? *reinterpret_cast<const uint32_t*>(g + M24(u * RPP, im.stride)) : 0u;
+        SVO_LDS(uint32_t)* t0 = (SVO_LDS(uint32_t)*)tile + r0 * KLT_J2S + 2 * c4;
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const uint32_t e7 = (v[u] & 0x00ff00ffu) << 7, o7 = ((v[u] >> 8) & 0x00ff00ffu) << 7;   // (p0, p2), (p1, p3), each << 7
+            const uint32_t ne7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e7, 0x101 /* row_shl:1 */, 0xF, 0xF, false);
+            if (c4 < nq && r0 + u * RPP < rows) {
+                SVO_LDS(uint32_t)* t = t0 + u * RPP * KLT_J2S;
+                t[0] = __builtin_amdgcn_perm(o7, e7, 0x05040100u);                 // (p0, p1)
+                t[1] = __builtin_amdgcn_perm(o7, e7, 0x07060302u);                 // (p2, p3)
+                t[KLT_J2COPY] = __builtin_amdgcn_perm(e7, o7, 0x07060100u);        // (p1, p2)
+                t[KLT_J2COPY + 1] = __builtin_amdgcn_perm(ne7, o7, 0x05040302u);   // (p3, p4): p4 from the next lane (unused in the last column)
+            }
+        }
+    } else {
+        const int tcol = tid & 63, trow0 = tid >> 6;
+        SVO_LDS(uint16_t)* t16 = (SVO_LDS(uint16_t)*)tile;
+        if (tcol < 4 * nq) {
+            const int gx = reflect101(x0 + tcol, im.w);
+            for (int r = trow0 * 8; r < rows; r += 8 * KLT_WAVES) {      // 8 independent loads in flight
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int gy = reflect101(y0 + min(r + u, rows - 1), im.h);
+                    v[u] = im.g()[M24(gy, im.stride) + gx];            // offsets < 2^31
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (r + u < rows) {
+                        const uint16_t pv = (uint16_t)((int)v[u] << 7);
+                        t16[(r + u) * 2 * KLT_J2S + tcol] = pv;
+                        if (tcol > 0) t16[2 * KLT_J2COPY + (r + u) * 2 * KLT_J2S + tcol - 1] = pv;
+                    }
+            }
+        }
+    }
+}
+
 // CW: threads per window row: 32 when w+1 <= 32 (2 row groups of 16 rows), else 36 (one group of 36
 // rows, 36 of the 64 threads). A thread owns column lc and the RPT consecutive rows from lr*RPT.
 // One wavefront per keypoint (KLT_THREADS = 64): no cross-wave barrier in the iteration, and a
@@ -192,9 +280,13 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     const int y0 = row_on ? lr * RPT : 0;
 
     __shared__ __attribute__((aligned(16))) uint8_t s_I[KLT_RROWS * KLT_RS];
-    __shared__ int s_d[(KLT_DW + 1) * KLT_DW];    // packed (dx, dy) int16; + one slack row
-    __shared__ __attribute__((aligned(16))) uint8_t s_J[KLT_TJROWS * KLT_TJS];
-    __shared__ double s_part[KLT_WAVES][4];
+    // s_d: packed (dx, dy) int16 at the tap positions (+ one slack row), only alive while the template is
+    // built; the search tile (two 16-bit copies) takes the same LDS afterwards
+    constexpr int KLT_SD = (KLT_DW + 1) * KLT_DW, KLT_SJ2 = KLT_J2COPY + KLT_TJROWS * KLT_J2S;
+    __shared__ __attribute__((aligned(16))) int s_dj[KLT_SD > KLT_SJ2 ? KLT_SD : KLT_SJ2];
+    int* const s_d = s_dj;
+    uint32_t* const s_J2 = reinterpret_cast<uint32_t*>(s_dj);
+    __shared__ double s_part[KLT_WAVES][8];
 
     // the keyframe record is wave-uniform: its fields are read where they are used. (A local copy of
     // the struct lands in scratch memory — 216 B per lane written and read back per keypoint, 0.7 GB
@@ -293,7 +385,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         // template of the thread's rows (registers) + covariance of the derivatives
         // (per-thread int32 partials: <= 36 pixels, each product < 2^24)
         int tIw[NPAIR], tIx[NPAIR], tIy[NPAIR];
-        int a11 = 0, a12 = 0, a22 = 0;
+        int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
         {
             const int lcs = col_on ? lc : 0;                             // keep idle columns in bounds
             // tile row y+1 holds image row iprevy+y
@@ -315,6 +407,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 int iyval = dot2(dyp, wt.top, dot2(dyp1, wt.bot, 1 << (W_BITS - 1))) >> W_BITS;
                 if (!(col_on && y < win)) { ival = 0; ixval = 0; iyval = 0; }
                 a11 += M24(ixval, ixval); a12 += M24(ixval, iyval); a22 += M24(iyval, iyval);
+                c1 += M24(ival, ixval); c2 += M24(ival, iyval);      // (|I| < 2^13, |dI| < 2^12, 18 rows: below 2^30)
                 iv[u & 1] = ival; ixv[u & 1] = ixval; iyv[u & 1] = iyval;
                 if (u & 1) {
                     tIw[u >> 1] = pack16(iv[0], iv[1]);
@@ -324,11 +417,12 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 dxp = dxp1; dyp = dyp1;
             }
         }
-        double sA[3];
+        double sA[5];
         {
-            const int pa[3] = {a11, a12, a22};
-            klt_block_sum<3>(pa, sA, s_part);
+            const int pa[5] = {a11, a12, a22, c1, c2};
+            klt_block_sum<5>(pa, sA, s_part);
         }
+        const double cI1 = sA[3], cI2 = sA[4];                    // sum I Ix, sum I Iy over the window
         const float A11 = (float)sA[0] * FLT_SCALE, A12 = (float)sA[1] * FLT_SCALE,
                     A22 = (float)sA[2] * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -349,17 +443,25 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         auto load_tile = [&](int cx, int cy) {
             tx0 = (cx - KLT_MARGIN) & ~3; ty0 = cy - KLT_MARGIN;
             __syncthreads();
-            stage_tile<KLT_TJS, KLT_TJROWS>(s_J, J, tx0, ty0, TW >> 2, TJ);
+            stage_tile_j2(s_J2, J, tx0, ty0, TW >> 2, TJ);
             __syncthreads();
             have_tile = true;
         };
-        // J(x+d) - I(x) of the thread's row pair k for the window whose rows were read into jr
-        auto row_pair_diff = [&](const int (&jr)[RPT + 1], const LkWeights& w, int k) -> v2s {
-            const int v0 = dot2(as_v2s(jr[2 * k]), w.top, dot2(as_v2s(jr[2 * k + 1]), w.bot, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            const int v1 = dot2(as_v2s(jr[2 * k + 1]), w.top, dot2(as_v2s(jr[2 * k + 2]), w.bot, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            return as_v2s(pack16(v0, v1)) - as_v2s(tIw[k]);
+        // J(x+d) of the thread's row pair k (5 fractional bits, like the template) for the window whose
+        // rows were read into jr: the tile holds pixel << 7, so (sum + 2^8) >> 9 is the high half of
+        // sum * 2^7 + 2^15, and the pair is the two high halves
+        auto row_pair = [&](const int (&jr)[RPT + 1], const LkWeights& w, int k) -> v2s {
+            const int d0 = dot2(as_v2s(jr[2 * k]), w.top, dot2(as_v2s(jr[2 * k + 1]), w.bot, 1 << (W_BITS - 5 - 1 + 7)));
+            const int d1 = dot2(as_v2s(jr[2 * k + 1]), w.top, dot2(as_v2s(jr[2 * k + 2]), w.bot, 1 << (W_BITS - 5 - 1 + 7)));
+            return as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
         };
-        const uint32_t jcol = lds_addr(&s_J[y0 * KLT_TJS + lc]);
+        // the bilinear pairs (p[x], p[x+1]) of the thread's column and rows for the window at tile offset (wx, wy)
+        auto load_pairs = [&](int wx, int wy, int (&jr)[RPT + 1]) {
+            const int x = wx + lc;
+            const SVO_LDS(uint32_t)* q = (const SVO_LDS(uint32_t)*)s_J2 + (x & 1) * KLT_J2COPY + (wy + y0) * KLT_J2S + (x >> 1);
+#pragma unroll
+            for (int u = 0; u <= RPT; u++) jr[u] = (int)q[u * KLT_J2S];
+        };
 
         for (int j = 0; j < 30; j++) {
             const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
@@ -370,15 +472,20 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             if (!have_tile || inextx < tx0 || inexty < ty0 || inextx + DW > tx0 + TW || inexty + DW > ty0 + TJ)
                 load_tile(inextx, inexty);
             wt = lk_weights(nextx - inextx, nexty - inexty);
+            // b = sum (J - I) dI = sum J dI - sum I dI: the second sum is a constant of the level (cI1, cI2)
             int b1 = 0, b2 = 0;
             if (col_on) {
                 int jr[RPT + 1];
-                lds_pairs<KLT_TJS, 0, 1>(jcol + (inexty - ty0) * KLT_TJS + (inextx - tx0), jr);
+                load_pairs(inextx - tx0, inexty - ty0, jr);
 #pragma unroll
                 for (int k = 0; k < NPAIR; k++) {
-                    const v2s diff = row_pair_diff(jr, wt, k);
-                    b1 = dot2(diff, as_v2s(tIx[k]), b1);      // rows outside the window have Ix = Iy = 0
-                    b2 = dot2(diff, as_v2s(tIy[k]), b2);
+#ifdef SVO_KLT_NOFOLD
+                    const v2s jv = row_pair(jr, wt, k) - as_v2s(tIw[k]);
+#else
+                    const v2s jv = row_pair(jr, wt, k);
+#endif
+                    b1 = dot2(jv, as_v2s(tIx[k]), b1);        // rows outside the window have Ix = Iy = 0
+                    b2 = dot2(jv, as_v2s(tIy[k]), b2);
                 }
             }
             double sB[2];
@@ -386,7 +493,12 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
                 const int pb[2] = {b1, b2};
                 klt_block_sum<2>(pb, sB, s_part);
             }
+#ifdef SVO_KLT_NOFOLD
             const float fb1 = (float)sB[0] * FLT_SCALE, fb2 = (float)sB[1] * FLT_SCALE;
+            (void)cI1; (void)cI2;
+#else
+            const float fb1 = (float)(sB[0] - cI1) * FLT_SCALE, fb2 = (float)(sB[1] - cI2) * FLT_SCALE;
+#endif
             const float dx = (float)((A12 * fb2 - A22 * fb1) * D);
             const float dy = (float)((A12 * fb1 - A11 * fb2) * D);
             nextx += dx; nexty += dy;
@@ -412,16 +524,21 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             int e = 0;
             if (col_on) {
                 int jr[RPT + 1];
-                lds_pairs<KLT_TJS, 0, 1>(jcol + (iny - ty0) * KLT_TJS + (inx - tx0), jr);
+                load_pairs(inx - tx0, iny - ty0, jr);
 #pragma unroll
                 for (int k = 0; k < NPAIR; k++) {
-                    const v2s diff = row_pair_diff(jr, wt, k);
+                    const v2s diff = row_pair(jr, wt, k) - as_v2s(tIw[k]);
                     if (y0 + 2 * k < win) e += abs((int)diff.x);
                     if (y0 + 2 * k + 1 < win) e += abs((int)diff.y);
                 }
             }
             // < 2^24: the float sum of |diff| is exact in any order
-            const float errval = (float)(KLT_WAVES == 1 ? wave_sum_bcast_i(e) : (int)[&] { double sE[1]; const int pe[1] = {e}; klt_block_sum<1>(pe, sE, s_part); return sE[0]; }());
+            double sE[1];
+            {
+                const int pe[1] = {e};
+                klt_block_sum<1>(pe, sE, s_part);
+            }
+            const float errval = (float)sE[0];
             err = errval * 1.f / (32 * win * win);
         }
     }

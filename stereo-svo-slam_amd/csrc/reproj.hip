@@ -165,8 +165,14 @@ __device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, con
     exponential_map(twist, grad);                  // not rotated (pose_refinement.cpp:398-411)
 }
 
+// (diagnostic builds: -DSVO_RP_OCC=n caps the registers at 512/n per lane)
+#ifdef SVO_RP_OCC
+#define RP_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_RP_OCC)))
+#else
+#define RP_OCC_ATTR
+#endif
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void reproj_gn_kernel(const ReprojArgs* __restrict__ args, int cap) {
+__global__ __launch_bounds__(64 * WAVES) RP_OCC_ATTR void reproj_gn_kernel(const ReprojArgs* __restrict__ args, int cap) {
     constexpr int T = 64 * WAVES;
     __builtin_amdgcn_s_setprio(3);     // latency-bound: win the issue arbitration against co-resident window kernels
     const ReprojArgs& a = args[blockIdx.x];
