@@ -39,7 +39,8 @@ constexpr int SSD_MAX_MH = 17, SSD_MAX_MW = 65; // match map: (2*search_y+1) x (
 constexpr int SSD_T_STRIDE = 96;                // bytes per padded template row: 16 zeros | row | zeros
 constexpr int SSD_R_STRIDE = 144;               // bytes per search-region row (36 dwords: conflict-free b128 rows)
 constexpr int SSD_R_ROWS = SSD_MAX_WIN + SSD_MAX_MH;   // 52
-constexpr int SSD_W_STRIDE = 100;               // ints per row of the column sums
+constexpr int SSD_W_STRIDE = 105;               // ints per row of the column sums (= 1 mod 8: the 8 rows x 8 segments of 8 columns
+                                                // that a wave reads in the row pass hit 64 different banks; 100 was a 4-way conflict)
 constexpr int SSD_MAX_MATCH = SSD_MAX_MW * SSD_MAX_MH;
 #ifndef SVO_SSD_THREADS
 #define SVO_SSD_THREADS 256
@@ -249,8 +250,10 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     const float minVal = (float)min_int;
 
     int sumj = 0, cnt = 0;
+    // o / mw without an integer division: exact for o * mw < 2^20 (the map has at most 65 x 17 entries)
+    const unsigned magic = ((1u << 20) + (unsigned)mw - 1u) / (unsigned)mw;
     for (int o = tid; o < nm; o += SSD_THREADS) {
-        const int k = o / mw, j = o % mw;
+        const int k = (int)(((unsigned)o * magic) >> 20), j = o - k * mw;
         if (j >= minx && k >= miny && (double)(float)s_m[o] <= (double)minVal) { sumj += j; cnt++; }
     }
     sumj = wave_sum_dpp_i(sumj);

@@ -161,7 +161,14 @@ __device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, con
 #pragma unroll
         for (int r = 0; r < 6; r++) e[r] = ((const SVO_LDS(float)*)sh.sums)[21 + r];
     }
+#ifdef SVO_SVD_ONE_LANE
+    // experiment: the solve under an exec mask of one lane, result broadcast
+    if (tid == 0) gn_solve6(H, e, twist, a.exact_pinv != 0);
+#pragma unroll
+    for (int q = 0; q < 6; q++) twist[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(twist[q])));
+#else
     gn_solve6(H, e, twist, a.exact_pinv != 0);
+#endif
     exponential_map(twist, grad);                  // not rotated (pose_refinement.cpp:398-411)
 }
 

@@ -85,7 +85,7 @@ constexpr int SIA_ACC_U = SVO_SIA_ACC_U;   // keypoints per trip of the ordered 
 enum { KF_PX = 0, KF_PY, KF_PZ, KF_QX, KF_QY, KF_GXX, KF_GXY, KF_GYY, KF_ACT, KF_COUNT };
 enum { REC_I1 = 0, REC_PS = 1, REC_G0 = 2, REC_G1 = 3 };
 struct SiaLds {
-    size_t img, tbuf, kpf, rec, sums, stage, total;
+    size_t img, tbuf, kpf, rec, sums, stage, pipe, total;
 };
 __host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, bool exact, int mode = 0) {
     SiaLds l;
@@ -94,8 +94,10 @@ __host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, 
     l.tbuf = off;  off += T == 64 ? 0 : (size_t)2 * cap * 4;             // one wave sums by v_readlane
     l.kpf = off;   off += mode == 2 ? 0 : (size_t)KF_COUNT * cap * 4;
     l.rec = off;   off += mode == 2 ? 0 : (size_t)(mode == 1 ? 16 : 64) * cap * 4;
-    l.sums = off;  off += (size_t)(T / 64) * 32 * 4;                   // [WAVES][32]
-    l.stage = off; off += exact ? (size_t)7 * (SIA_STG * 20 + 4) * 4 : 0;   // 7 planes of SIA_STG keypoints' rows (20 floats each)
+    l.sums = off;  off += (size_t)(T / 64) * 32 * 4 + 32;              // [WAVES][32] + the step wave 0 hands to the others
+    // 7 planes of SIA_STG keypoints' rows (20 floats each); several waves per sequence fill two of them in turn
+    l.stage = off; off += exact ? (size_t)(T > 128 ? 2 : 1) * 7 * (SIA_STG * 20 + 4) * 4 : 0;
+    l.pipe = off;  off += exact && T > 128 ? 16 : 0;                   // hand-over counters of the two buffers
     l.total = off;
     return l;
 }
@@ -359,12 +361,11 @@ struct Sia {
         constexpr int PS = SIA_STG * KS + 4;         // plane stride: the 7 planes start on different banks
         float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index slot*KS + px
 
-        for (int i0 = 0; i0 < npad; i0 += T) {
-            const int i = i0 + tid;
-            float J[12];
+        // J (2x6) and the 16 residuals of keypoint i (a lane's work of one pass)
+        auto compute_kp = [&](int i, float (&J)[12], float (&d)[16], bool& active) {
 #pragma unroll
             for (int q = 0; q < 12; q++) J[q] = 0;
-            const bool active = kpf_ld(KF_ACT, i) != 0.f;
+            active = kpf_ld(KF_ACT, i) != 0.f;
             if (active) {
                 float X[3] = {kpf_ld(KF_PX, i) - pm.t[0], kpf_ld(KF_PY, i) - pm.t[1], kpf_ld(KF_PZ, i) - pm.t[2]};
                 mat33f_vec(pm.Ri, X, X);
@@ -375,7 +376,6 @@ struct Sia {
             // clamped to the image) and every patch sum whose taps start where the walk says they
             // should — all of them, unless a float increment rounds across an integer — takes its 3x3
             // taps from the block; the others read the image directly.
-            float d[16];
             {
                 const float kx0 = kpf_ld(KF_QX, i) - 2.f, ky0 = kpf_ld(KF_QY, i) - 2.f;
                 const int bx = (int)fminf(fmaxf(floorf(kx0 - 0.5f), -8.f), 65536.f);
@@ -425,6 +425,108 @@ struct Sia {
                     ky += 1.f;
                 }
             }
+        };
+        // one keypoint's rows of gradient_times_jacobians (:376-388) and its diffs into slot `slot` of a staging buffer
+        auto stage_kp = [&](float* stg, int slot, int i, bool active, const float (&J)[12], const float (&d)[16]) {
+#pragma unroll
+            for (int p4 = 0; p4 < 4; p4++) {
+                float g0[4], g1[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    g0[e] = active ? rec_ld(REC_G0, p4 * 4 + e, i) : 0.f;
+                    g1[e] = active ? rec_ld(REC_G1, p4 * 4 + e, i) : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    v4f row;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float sum = 0;
+                        sum += g0[e] * J[q];
+                        sum += g1[e] * J[6 + q];
+                        row[e] = sum;
+                    }
+                    *(SVO_LDS(v4f)*)(LDSF(stg) + q * PS + slot * KS + p4 * 4) = row;
+                }
+                // residual -= row * diff (:472-477) == residual += row * (-diff), exactly
+                *(SVO_LDS(v4f)*)(LDSF(stg) + 6 * PS + slot * KS + p4 * 4) =
+                    v4f{-d[p4 * 4], -d[p4 * 4 + 1], -d[p4 * 4 + 2], -d[p4 * 4 + 3]};
+            }
+        };
+        // hessian += row^T row (lanes 0..20), residual += row * (-diff) (lanes 21..26) over the m keypoints of a
+        // staging buffer: one multiply and one add of the chain per patch pixel, in storage order. SIA_ACC_U keypoints
+        // per trip: their LDS reads are in flight together and the chain starts when the first arrive. (Slots past
+        // m up to the next multiple of SIA_ACC_U were staged as zeros like every keypoint that takes no part: they
+        // add exact zeros.) Products two at a time (v_pk_mul_f32: the same IEEE products), the adds in storage order.
+        auto accumulate_chunk = [&](const float* stg, int m) {
+            const SVO_LDS(float)* pa = LDSCF(stg) + ia * PS;
+            const SVO_LDS(float)* pb = LDSCF(stg) + ib * PS;
+            for (int j = 0; j < m; j += SIA_ACC_U) {
+                v4f ra[SIA_ACC_U][4], rb[SIA_ACC_U][4];
+#pragma unroll
+                for (int u = 0; u < SIA_ACC_U; u++) {
+                    const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + (j + u) * KS);
+                    const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + (j + u) * KS);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { ra[u][e] = qa[e]; rb[u][e] = qb[e]; }
+                }
+#pragma unroll
+                for (int u = 0; u < SIA_ACC_U; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const v2f p0 = ra[u][e].lo * rb[u][e].lo, p1 = ra[u][e].hi * rb[u][e].hi;
+                        eacc += p0.x; eacc += p0.y; eacc += p1.x; eacc += p1.y;
+                    }
+            }
+        };
+
+        if (WAVES > 2 && exact) {
+            // ---- reference-order accumulation as a pipeline (four waves per sequence): wave 0 only adds,
+            // chunk after chunk of SIA_STG keypoints in index order; the other waves compute the keypoints
+            // (Jacobian, residuals, rows) and fill the two staging buffers ahead of it. Hand-over through LDS
+            // counters (a buffer's k-th fill may start when its (k-1)-th has been read). The chain of adds in
+            // wave 0 — sequential by definition — is what a gradient call then costs.
+            static_assert(SIA_STG == 64, "the pipelined accumulation hands over whole waves of keypoints");
+            SVO_LDS(int)* cnt = (SVO_LDS(int)*)(dyn + lay.pipe);       // [0..1] fills done, [2..3] reads done, per buffer
+            float* const stg0 = stage;
+            float* const stg1 = stage + 7 * PS;
+            if (tid < 4) cnt[tid] = 0;
+            __syncthreads();
+            const int n_chunks = (n + SIA_STG - 1) / SIA_STG;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the two roles never share a wave)
+            if (wave == 0) {
+                for (int c = 0; c < n_chunks; c++) {
+                    const int bsel = c & 1, k = c >> 1;
+                    while (__hip_atomic_load(&cnt[bsel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (lane < 27) accumulate_chunk(bsel ? stg1 : stg0, min(SIA_STG, n - c * SIA_STG));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&cnt[2 + bsel], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                for (int c = wave - 1; c < n_chunks; c += WAVES - 1) {
+                    const int i = c * SIA_STG + lane;
+                    float J[12], d[16];
+                    bool active;
+#pragma unroll
+                    for (int q = 0; q < 12; q++) J[q] = 0;
+                    compute_kp(i, J, d, active);
+                    const int bsel = c & 1, k = c >> 1;
+                    while (__hip_atomic_load(&cnt[2 + bsel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    stage_kp(bsel ? stg1 : stg0, lane, i, active, J, d);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&cnt[bsel], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        } else
+        for (int i0 = 0; i0 < npad; i0 += T) {
+            const int i = i0 + tid;
+            float J[12], d[16];
+            bool active;
+#pragma unroll
+            for (int q = 0; q < 12; q++) J[q] = 0;
+            compute_kp(i, J, d, active);
             if (!exact) {
                 float s0 = 0, s1 = 0, Gxx = 0, Gxy = 0, Gyy = 0;
                 if (active) {                               // (slots past the keypoints hold no records)
@@ -450,76 +552,10 @@ struct Sia {
                 // diffs, keypoint-major; wave 0 adds them in storage order.
                 for (int sub = 0; sub < T / SIA_STG; sub++) {
                     sia_sync<WAVES>();                      // the previous keypoints have been consumed
-                    if ((tid / SIA_STG) == sub) {
-                        const int slot = tid % SIA_STG;
-#pragma unroll
-                        for (int p4 = 0; p4 < 4; p4++) {
-                            float g0[4], g1[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                g0[e] = active ? rec_ld(REC_G0, p4 * 4 + e, i) : 0.f;
-                                g1[e] = active ? rec_ld(REC_G1, p4 * 4 + e, i) : 0.f;
-                            }
-#pragma unroll
-                            for (int q = 0; q < 6; q++) {
-                                v4f row;
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    float sum = 0;
-                                    sum += g0[e] * J[q];
-                                    sum += g1[e] * J[6 + q];
-                                    row[e] = sum;
-                                }
-                                *(SVO_LDS(v4f)*)(LDSF(stage) + q * PS + slot * KS + p4 * 4) = row;
-                            }
-                            // residual -= row * diff (:472-477) == residual += row * (-diff), exactly
-                            *(SVO_LDS(v4f)*)(LDSF(stage) + 6 * PS + slot * KS + p4 * 4) =
-                                v4f{-d[p4 * 4], -d[p4 * 4 + 1], -d[p4 * 4 + 2], -d[p4 * 4 + 3]};
-                        }
-                    }
+                    if ((tid / SIA_STG) == sub) stage_kp(stage, tid % SIA_STG, i, active, J, d);
                     sia_sync<WAVES>();
-                    if (wave == 0 && lane < 27) {
-                        const int m = min(SIA_STG, n - (i0 + sub * SIA_STG));   // keypoints of this chunk, in index order
-                        const SVO_LDS(float)* pa = LDSCF(stage) + ia * PS;
-                        const SVO_LDS(float)* pb = LDSCF(stage) + ib * PS;
-                        // hessian += row^T row (lanes 0..20), residual += row * (-diff) (lanes 21..26):
-                        // one multiply and one add of the chain per patch pixel, in storage order. The
-                        // rows of keypoint j + 1 are on their way from LDS while those of j are added.
-                        // Four keypoints per trip: their 32 LDS reads are in flight together and the chain
-                        // starts when the first arrive. (Slots past m up to the next multiple of four were
-                        // staged as zeros like every keypoint that takes no part: they add exact zeros.)
-#ifdef SVO_SIA_ACC1
-                        for (int j = 0; j < m; j++) {       // (bisecting aid: one keypoint per trip)
-                            const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + j * KS);
-                            const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + j * KS);
-                            const v4f a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-                            const v4f b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-                            eacc += a0.x * b0.x; eacc += a0.y * b0.y; eacc += a0.z * b0.z; eacc += a0.w * b0.w;
-                            eacc += a1.x * b1.x; eacc += a1.y * b1.y; eacc += a1.z * b1.z; eacc += a1.w * b1.w;
-                            eacc += a2.x * b2.x; eacc += a2.y * b2.y; eacc += a2.z * b2.z; eacc += a2.w * b2.w;
-                            eacc += a3.x * b3.x; eacc += a3.y * b3.y; eacc += a3.z * b3.z; eacc += a3.w * b3.w;
-                        }
-#else
-                        for (int j = 0; j < m; j += SIA_ACC_U) {
-                            v4f ra[SIA_ACC_U][4], rb[SIA_ACC_U][4];
-#pragma unroll
-                            for (int u = 0; u < SIA_ACC_U; u++) {
-                                const SVO_LDS(v4f)* qa = (const SVO_LDS(v4f)*)(pa + (j + u) * KS);
-                                const SVO_LDS(v4f)* qb = (const SVO_LDS(v4f)*)(pb + (j + u) * KS);
-#pragma unroll
-                                for (int e = 0; e < 4; e++) { ra[u][e] = qa[e]; rb[u][e] = qb[e]; }
-                            }
-                            // products two at a time (v_pk_mul_f32: the same IEEE products), the adds in storage order
-#pragma unroll
-                            for (int u = 0; u < SIA_ACC_U; u++)
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    const v2f p0 = ra[u][e].lo * rb[u][e].lo, p1 = ra[u][e].hi * rb[u][e].hi;
-                                    eacc += p0.x; eacc += p0.y; eacc += p1.x; eacc += p1.y;
-                                }
-                        }
-#endif
-                    }
+                    if (wave == 0 && lane < 27)
+                        accumulate_chunk(stage, min(SIA_STG, n - (i0 + sub * SIA_STG)));   // keypoints of this chunk, in index order
                 }
             }
         }
@@ -563,6 +599,24 @@ struct Sia {
         }
         SIA_T(g2);
         float delta[6], pg[6];
+        if (WAVES > 2) {
+            // four waves: wave 0 solves, the others wait at the barrier (the same 6x6 SVD in every wave would
+            // only take VALU time from the kernels of the other sequence groups)
+            if (wave == 0) {
+                gn_solve6(H, b, delta, exact);
+                exponential_map(delta, pg);
+                mat33f_vec(pm.R, pg, grad);
+                mat33f_vec(pm.R, pg + 3, grad + 3);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) LDSF(sums)[WAVES * 32 + q] = grad[q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; q++) grad[q] = LDSCF(sums)[WAVES * 32 + q];
+            __syncthreads();                             // (sums is written again by the next call)
+        } else {
 #ifdef SVO_SVD_ONE_LANE
         // experiment: the solve under an exec mask of one lane (less switching power), result broadcast
         if (lane == 0) gn_solve6(H, b, delta, exact);
@@ -574,6 +628,7 @@ struct Sia {
         exponential_map(delta, pg);
         mat33f_vec(pm.R, pg, grad);                  // pose_estimator.cpp:495-497
         mat33f_vec(pm.R, pg + 3, grad + 3);
+        }
         SIA_T(g3);
         SIA_ADD(5, g1, g0); SIA_ADD(6, g2, g1); SIA_ADD(7, g3, g2); SIA_ADD(8, 1, 0);
 #ifndef SVO_SIA_STAMPS
