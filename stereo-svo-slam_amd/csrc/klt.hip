@@ -152,6 +152,17 @@ __device__ inline int cv_round(float v) { return (int)rintf(v); }
 __device__ inline int cv_floor(float v) { return (int)floorf(v); }
 
 struct LkWeights { v2s top, bot; };
+
+// one keypoint's template of one pyramid level in HBM (KfDev::tmpl): TQ x 64 uint4 (lane-major:
+// q * 64 + lane, a coalesced 1 KB per load instruction) = the NPAIR int16 pairs of I, Ix, Iy of every lane,
+// then this header
+enum { KLT_OUTSIDE = 0, KLT_FLAT = 1, KLT_TRACK = 2 };    // reference window outside the image / minEig below the threshold
+struct KltTmplHeader { int state; float A11, A12, A22; double cI1, cI2; };
+template <int NPAIR>
+struct KltTmpl {
+    static constexpr int TQ = (3 * NPAIR + 3) / 4;
+    static constexpr int BYTES = TQ * 64 * 16 + 64;
+};
 // the four 14-bit bilinear weights of calcOpticalFlowPyrLK for the fractions (fa, fb)
 __device__ inline LkWeights lk_weights(float fa, float fb) {
     const int W_BITS = 14;
@@ -322,6 +333,10 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         nx = q.x; ny = q.y;
     }
 
+    // template cache of the keyframe (tracker only; null: templates are built every frame)
+    const uint8_t* tmpl_base = (a.proj_pose && kfp->tmpl_win == a.win) ? (const uint8_t*)kfp->tmpl : nullptr;
+    const int tmpl_cap = kfp->tmpl_cap;
+    const int kpi = a.proj_pose ? __builtin_amdgcn_readfirstlane(G(a.kp_index)[kp]) : 0;
     const int maxLevel = min(kfp->n_lk, a.n_cur) - 1;
     const float halfWin = (win - 1) * 0.5f;
     const int W_BITS = 14;
@@ -341,13 +356,43 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         else { nx = nx * 2.f; ny = ny * 2.f; }
         float nextx = nx, nexty = ny;
 
+        // ---- the template of the level: I, Ix, Iy of the reference window at its sub-pixel position (the
+        // thread's rows, int16 pairs in registers), the covariance matrix of the derivatives and the sums
+        // sum I Ix / sum I Iy. They depend on the KEYFRAME only (its pyramid and the keypoint's position
+        // there never change), so a tracker keeps them in HBM from the first frame that builds them
+        // (KfDev::tmpl, 6 KB per keypoint and level — 288 GB is what makes that a cheap trade) and later
+        // frames load them: 6 x 16 B per lane instead of ~1000 VALU + 450 scalar instructions of tile
+        // staging, Scharr, interpolation and window sums per level. The same values either way.
+        int tIw[NPAIR], tIx[NPAIR], tIy[NPAIR];
+        float A11 = 0, A12 = 0, A22 = 0;
+        double cI1 = 0, cI2 = 0;
+        int lstate = KLT_TRACK;
+        LkWeights wt;
+        SVO_GP(uint4) rec = nullptr;
+        SVO_GP(uint8_t) vflag = nullptr;
+        if (tmpl_base && kpi < tmpl_cap) {
+            rec = (SVO_GP(uint4))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level) * KltTmpl<NPAIR>::BYTES);
+            vflag = G(kfp->tmpl_valid) + kpi * SVO_LK_LEVELS + level;
+        }
+        const bool hit = vflag && *vflag != 0;
+        if (hit) {
+            SVO_GP(const KltTmplHeader) hd = (SVO_GP(const KltTmplHeader))(rec + KltTmpl<NPAIR>::TQ * 64);
+            lstate = hd->state; A11 = hd->A11; A12 = hd->A12; A22 = hd->A22; cI1 = hd->cI1; cI2 = hd->cI2;
+            if (lstate == KLT_TRACK) {
+                uint4 v[KltTmpl<NPAIR>::TQ];
+#pragma unroll
+                for (int q = 0; q < KltTmpl<NPAIR>::TQ; q++) v[q] = rec[q * 64 + tid];
+                const uint32_t* f = reinterpret_cast<const uint32_t*>(v);
+#pragma unroll
+                for (int k = 0; k < NPAIR; k++) { tIw[k] = (int)f[k]; tIx[k] = (int)f[NPAIR + k]; tIy[k] = (int)f[2 * NPAIR + k]; }
+            }
+        } else {
         prevx -= halfWin; prevy -= halfWin;
         const int iprevx = cv_floor(prevx), iprevy = cv_floor(prevy);
         if (iprevx < -win || iprevx >= I.w || iprevy < -win || iprevy >= I.h) {
-            if (level == 0) { status = 0; err = 0; }
-            continue;
-        }
-        LkWeights wt = lk_weights(prevx - iprevx, prevy - iprevy);
+            lstate = KLT_OUTSIDE;
+        } else {
+        wt = lk_weights(prevx - iprevx, prevy - iprevy);
 
         __syncthreads();
         // (w+3)^2 tile of I around the window: rows iprevy-1 .., columns from the dword boundary left of iprevx-1
@@ -384,7 +429,6 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
 
         // template of the thread's rows (registers) + covariance of the derivatives
         // (per-thread int32 partials: <= 36 pixels, each product < 2^24)
-        int tIw[NPAIR], tIx[NPAIR], tIy[NPAIR];
         int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
         {
             const int lcs = col_on ? lc : 0;                             // keep idle columns in bounds
@@ -422,16 +466,40 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             const int pa[5] = {a11, a12, a22, c1, c2};
             klt_block_sum<5>(pa, sA, s_part);
         }
-        const double cI1 = sA[3], cI2 = sA[4];                    // sum I Ix, sum I Iy over the window
-        const float A11 = (float)sA[0] * FLT_SCALE, A12 = (float)sA[1] * FLT_SCALE,
-                    A22 = (float)sA[2] * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
+        cI1 = sA[3]; cI2 = sA[4];                                 // sum I Ix, sum I Iy over the window
+        A11 = (float)sA[0] * FLT_SCALE; A12 = (float)sA[1] * FLT_SCALE; A22 = (float)sA[2] * FLT_SCALE;
+        const float D0 = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                              (2 * win * win);
-        if ((double)minEig < 1e-4 || D < FLT_EPSILON) {
+        if ((double)minEig < 1e-4 || D0 < FLT_EPSILON) lstate = KLT_FLAT;
+        }   // reference window inside the image
+        if (vflag) {                       // first frame that sees this keypoint at this level: keep the template
+            if (lstate == KLT_TRACK) {
+                uint4 v[KltTmpl<NPAIR>::TQ];
+                uint32_t* f = reinterpret_cast<uint32_t*>(v);
+#pragma unroll
+                for (int k = 0; k < 4 * KltTmpl<NPAIR>::TQ; k++) f[k] = 0;
+#pragma unroll
+                for (int k = 0; k < NPAIR; k++) { f[k] = (uint32_t)tIw[k]; f[NPAIR + k] = (uint32_t)tIx[k]; f[2 * NPAIR + k] = (uint32_t)tIy[k]; }
+#pragma unroll
+                for (int q = 0; q < KltTmpl<NPAIR>::TQ; q++) rec[q * 64 + tid] = v[q];
+            }
+            if (tid == 0) {
+                SVO_GP(KltTmplHeader) hd = (SVO_GP(KltTmplHeader))(rec + KltTmpl<NPAIR>::TQ * 64);
+                hd->state = lstate; hd->A11 = A11; hd->A12 = A12; hd->A22 = A22; hd->cI1 = cI1; hd->cI2 = cI2;
+                *vflag = 1;                // (read by later launches only: ordered by the kernel boundary)
+            }
+        }
+        }   // template built here
+        if (lstate == KLT_OUTSIDE) {
+            if (level == 0) { status = 0; err = 0; }
+            continue;
+        }
+        if (lstate == KLT_FLAT) {
             if (level == 0) status = 0;
             continue;
         }
+        float D = A11 * A22 - A12 * A12;
         D = 1.f / D;
         nextx -= halfWin; nexty -= halfWin;
         float prevDx = 0, prevDy = 0;
@@ -463,7 +531,10 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
             for (int u = 0; u <= RPT; u++) jr[u] = (int)q[u * KLT_J2S];
         };
 
-        for (int j = 0; j < 30; j++) {
+#ifndef SVO_KLT_MAXIT
+#define SVO_KLT_MAXIT 30     /* (diagnostic builds count the instructions outside the iteration with 0) */
+#endif
+        for (int j = 0; j < SVO_KLT_MAXIT; j++) {
             const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
             if (inextx < -win || inextx >= J.w || inexty < -win || inexty >= J.h) {
                 if (level == 0) status = 0;
@@ -548,6 +619,11 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         G(a.status)[kp] = (uint8_t)status;
         G(a.err)[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
     }
+}
+
+// bytes of one keypoint's template of one level for window `win` (KfDev::tmpl)
+size_t klt_template_bytes(int win) {
+    return win + 1 <= 32 ? KltTmpl<8>::BYTES : KltTmpl<18>::BYTES;
 }
 
 void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream) {

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -185,6 +186,8 @@ struct Seq {
     float* sia_rec = nullptr;        // per-level alignment records (sia_prep_kernel)
     float* sia_kpws = nullptr;
     PoseMats* sia_mats = nullptr;    // rotation matrices of the aligned pose (sia_gn_kernel -> klt_track_kernel)
+    uint8_t* tmpl_base = nullptr;    // KLT template cache: tmpl_kf blocks (a ring over the sequence's keyframes)
+    uint8_t* tmpl_valid = nullptr;   // their "stored" flags
     KfDev* d_kfs = nullptr;
     std::vector<KfHost> kfs;
     DetCell* det = nullptr; int* n_det = nullptr;
@@ -305,6 +308,11 @@ struct svo_group {
     std::vector<void*> allocs;   // everything to free
     std::vector<uint8_t*> kf_slabs;   // free per-keyframe keypoint storage (allocated in chunks)
     std::vector<uint8_t*> set_slabs;  // free image-set storage (allocated in chunks)
+    // KLT template cache (klt.hip): the templates of a keyframe's keypoints stay in HBM while the keyframe is one
+    // of the last tmpl_kf of its sequence (0: off)
+    int tmpl_kf = 0, tmpl_cap = 0;
+    size_t tmpl_block_bytes = 0, tmpl_valid_bytes = 0;
+    void** h_null = nullptr;          // pinned null pointer (evicting a keyframe's cache)
     svo_totals totals;
     HostPool* pool = nullptr;
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
@@ -472,6 +480,19 @@ int new_keyframe_storage(svo_group* c, Seq& q, int s, int id) {
     d.kps2d = k.kps2d; d.kps3d = k.kps3d; d.flags = k.flags; d.outlier_count = k.outl; d.inlier_count = k.inl;
     d.kf_id = k.kf_id; d.kp_index = k.kp_index; d.score = k.score; d.level_type = k.level_type;
     d.color = k.color; d.kfx = k.kfx; d.kfP = k.kfP;
+    if (c->tmpl_kf > 0) {
+        // the keyframe takes the oldest block of the sequence's ring: flags cleared, and the keyframe that
+        // held the block (id - tmpl_kf) loses its cache (its points are tracked from the images again)
+        const int r = id % c->tmpl_kf;
+        d.tmpl = q.tmpl_base + (size_t)r * c->tmpl_block_bytes;
+        d.tmpl_valid = q.tmpl_valid + (size_t)r * c->tmpl_valid_bytes;
+        d.tmpl_cap = c->tmpl_cap;
+        d.tmpl_win = c->cam.window_size_opt_flow;
+        HIP_TRY(hipMemsetAsync(d.tmpl_valid, 0, c->tmpl_valid_bytes, c->stream));
+        if (id >= c->tmpl_kf)
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<uint8_t*>(q.d_kfs + (id - c->tmpl_kf)) + offsetof(KfDev, tmpl), c->h_null,
+                                   sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(q.d_kfs + id, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
     return SVO_OK;
 }
@@ -639,6 +660,33 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
         }
     }
     if ((rc = grow_kf_slabs(c, std::max(2 * B, 32)))) return rc;   // the first keyframes never allocate
+    {
+        // KLT template cache: SVO_KLT_CACHE_KF keyframes per sequence (default 4, 0 = off), as many as fit a
+        // third of the free device memory. A keypoint index beyond tmpl_cap (more points than grid cells + 64 in
+        // the frame that made the keyframe) is tracked without the cache.
+        int K = 4;
+        if (const char* e = std::getenv("SVO_KLT_CACHE_KF")) K = std::max(0, std::min(std::atoi(e), 64));
+        const int cells_ = (width / cam->grid_width) * (height / cam->grid_height);
+        c->tmpl_cap = std::min(c->cap, cells_ + 64);
+        c->tmpl_block_bytes = align_up((size_t)c->tmpl_cap * SVO_LK_LEVELS * klt_template_bytes(cam->window_size_opt_flow), 256);
+        c->tmpl_valid_bytes = align_up((size_t)c->tmpl_cap * SVO_LK_LEVELS, 256);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        while (K > 0 && (size_t)B * K * c->tmpl_block_bytes > free_b / 3) K--;
+        c->tmpl_kf = K;
+        if (K > 0) {
+            uint8_t* base = nullptr; uint8_t* vbase = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), (size_t)B * K * c->tmpl_block_bytes));
+            c->allocs.push_back(base);
+            if ((rc = dev_alloc(c, &vbase, (size_t)B * K * c->tmpl_valid_bytes))) return rc;
+            for (int s = 0; s < B; s++) {
+                c->seqs[s].tmpl_base = base + (size_t)s * K * c->tmpl_block_bytes;
+                c->seqs[s].tmpl_valid = vbase + (size_t)s * K * c->tmpl_valid_bytes;
+            }
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_null), 64, hipHostMallocDefault));
+            std::memset(c->h_null, 0, 64);
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return SVO_OK;
@@ -657,6 +705,7 @@ static int grp_destroy(svo_group* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_args) (void)hipHostFree(c->h_args);
     if (c->h_res) (void)hipHostFree(c->h_res);   // one pinned block: results, counts, inside counters
+    if (c->h_null) (void)hipHostFree(c->h_null);
     for (int i = 0; i < 10; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     // ImageSet structs: owned by the free lists, the current/previous pointers and keyframes

@@ -69,6 +69,11 @@ struct KfDev {                    // one keyframe as the device sees it
     // the rest of frame.kps.info as copied at creation (keyframe_manager.cpp:27): read by the getters only
     int* kf_id; int* kp_index; float* score; int* level_type; uint32_t* color; float* kfx; float* kfP;
     int n;
+    // KLT template cache (klt.hip): [tmpl_cap][SVO_LK_LEVELS] records of klt_template_bytes(tmpl_win) and their
+    // "stored" flags; null when the keyframe has none (stage API, or evicted from the sequence's ring)
+    void* tmpl;
+    uint8_t* tmpl_valid;
+    int tmpl_cap, tmpl_win;
 };
 
 struct KltArgs {
@@ -92,6 +97,7 @@ struct KltArgs {
     svo_camera_settings cam;
 };
 void launch_klt(const KltArgs* d_args, int batch, int max_n, int win, hipStream_t stream);
+size_t klt_template_bytes(int win);
 
 // ------------------------------------------- merge + reprojection GN (B1,B3)
 struct ReprojArgs {

@@ -35,6 +35,24 @@ def weighted_durations(stats_csv):
     return {k: tot[k] / calls[k] for k in tot}
 
 
+def call_counts(stats_csv):
+    calls = collections.defaultdict(float)
+    for r in csv.DictReader(open(stats_csv)):
+        if "svo::" in r["Name"]:
+            calls[short(r["Name"])] += float(r["Calls"])
+    return calls
+
+
+def valu_per_frame(sq, calls, seqs_per_launch):
+    """VALU wave-instructions of one tracked frame of one sequence: every kernel's mean per dispatch x its
+    dispatches, over the alignment launches (one per group and step) x the sequences of a launch."""
+    steps = calls.get("sia_gn_kernel", 0.0)
+    if steps <= 0:
+        return None
+    total = sum(c.get("SQ_INSTS_VALU", 0.0) * calls.get(k, 0.0) for k, c in sq.items())
+    return total / (steps * seqs_per_launch)
+
+
 SERIAL = ("sia_gn_kernel", "reproj_gn_kernel")     # one or a few waves per sequence, a serial chain
 
 
@@ -76,6 +94,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "reclassify":
         sq[r["kernel"]][r["counter"]] = float(r["mean_per_dispatch"])
     old = json.load(open(f"{src}/pmc.json"))
     old["kernels"] = classify(sq, weighted_durations(f"{src}/kernel_stats.csv"))
+    old["valu_instructions_per_frame"] = valu_per_frame(sq, call_counts(f"{src}/kernel_stats.csv"), old["seqs"] / old["groups"])
     json.dump(old, open(f"{out}/pmc.json", "w"), indent=1)
     print(json.dumps({k: {"bound": v["bound"], "frac": round(v["frac"], 4)} for k, v in old["kernels"].items()}, indent=1))
     sys.exit(0)
@@ -92,6 +111,7 @@ kernels = classify(sq, dur)
 cfg = bench["config"]
 meta = {"config": bench["config"]["workload"].split(":")[0], "seqs": cfg["sequences_per_gpu"], "groups": cfg["sequence_groups"]}
 json.dump({**meta, "kernels": kernels,
+           "valu_instructions_per_frame": valu_per_frame(sq, call_counts(f"{out}/kernel_stats.csv"), meta["seqs"] / meta["groups"]),
            "note": "rocprofv3 --pmc SQ_* pass of the default bench command (own run, kernel-include-regex svo); "
                    "durations from the --kernel-trace --stats run of the same command"},
           open(f"{out}/pmc.json", "w"), indent=1)

@@ -25,6 +25,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "$C pass done"
 done
 python3 tools/make_pmc_json.py /tmp/rp_$TAG "$OUT"
+# kernel times alone on the GPU: one sequence group of 256
+SVO_GROUPS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/kt1 -- python3 bench.py --no-cpu-baseline --no-extras --repeats 1 --seqs 256 --loops 16 --steps 40 > /dev/null 2> "$OUT/kt1.err"
+find /tmp/rp_$TAG/kt1 -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_1group_256seq.csv" \;
+echo "alone pass done"
 # diagnostic passes (what the co-running kernels compete for); a counter the device does not have fails its own pass only
 for SET in "SQ_BUSY_CYCLES SQ_LEVEL_WAVES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"; do
   N=$(echo $SET | cut -d" " -f1)
