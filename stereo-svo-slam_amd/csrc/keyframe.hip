@@ -97,6 +97,8 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
         if (keep) copy_kp(a.dst, pos++, a.src, i);
     }
     if (tid == 0) *G(a.dst.n) = total;
+    if (a.zero)
+        for (int i = tid; i < a.zero_count; i += blockDim.x) G(a.zero)[i] = 0;
 }
 
 // Small sets run with 256 threads: a 16-wave workgroup only starts on a CU that has drained, and
@@ -349,7 +351,13 @@ __global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restri
     __shared__ int s_cnt[4];
     float pose[6];
     for (int i = 0; i < 6; i++) pose[i] = a.first_frame ? 0.f : G(a.frame_pose)[i];
-    if (tid == 0) pose_mats(pose, pm);
+    if (tid == 0) {
+        pose_mats(pose, pm);
+        G(a.kfs)[a.new_kf_id] = a.record;                       // the keyframe table entry (pointers; n and pose below)
+        if (a.evict_id >= 0) G(a.kfs)[a.evict_id].tmpl = nullptr;   // its template cache block now belongs to the new keyframe
+    }
+    if (a.record.tmpl_valid)
+        for (int i = tid; i < a.tmpl_valid_bytes / 4; i += 256) ((SVO_GP(uint32_t))a.record.tmpl_valid)[i] = 0u;
     __syncthreads();
     const float fx = a.cam.fx, fy = a.cam.fy, cx = a.cam.cx, cy = a.cam.cy, baseline = a.cam.baseline;
     const uint32_t lcg0 = *G(a.color_lcg);
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void kf_init_kernel(const KfInitArgs* __restri
     }
     __syncthreads();
     // keyframe.kps = frame.kps; keyframe.pose = frame.pose (keyframe_manager.cpp:27-29)
-    const KfDev kf = G(a.kfs)[a.new_kf_id];   // the pointers of the record (scalar loads)
+    const KfDev& kf = a.record;               // the pointers of the record (scalar loads)
     int not_temp = 0;
     for (int i = tid; i < n; i += 256) {
         const uint32_t f = G(a.kps.flags)[i];

@@ -312,7 +312,6 @@ struct svo_group {
     // of the last tmpl_kf of its sequence (0: off)
     int tmpl_kf = 0, tmpl_cap = 0;
     size_t tmpl_block_bytes = 0, tmpl_valid_bytes = 0;
-    void** h_null = nullptr;          // pinned null pointer (evicting a keyframe's cache)
     svo_totals totals;
     HostPool* pool = nullptr;
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
@@ -481,19 +480,16 @@ int new_keyframe_storage(svo_group* c, Seq& q, int s, int id) {
     d.kf_id = k.kf_id; d.kp_index = k.kp_index; d.score = k.score; d.level_type = k.level_type;
     d.color = k.color; d.kfx = k.kfx; d.kfP = k.kfP;
     if (c->tmpl_kf > 0) {
-        // the keyframe takes the oldest block of the sequence's ring: flags cleared, and the keyframe that
-        // held the block (id - tmpl_kf) loses its cache (its points are tracked from the images again)
+        // the keyframe takes the oldest block of the sequence's ring; kf_init_kernel clears the flags and
+        // takes the cache away from the keyframe that held the block (id - tmpl_kf: its points are tracked
+        // from the images again)
         const int r = id % c->tmpl_kf;
         d.tmpl = q.tmpl_base + (size_t)r * c->tmpl_block_bytes;
         d.tmpl_valid = q.tmpl_valid + (size_t)r * c->tmpl_valid_bytes;
         d.tmpl_cap = c->tmpl_cap;
         d.tmpl_win = c->cam.window_size_opt_flow;
-        HIP_TRY(hipMemsetAsync(d.tmpl_valid, 0, c->tmpl_valid_bytes, c->stream));
-        if (id >= c->tmpl_kf)
-            HIP_TRY(hipMemcpyAsync(reinterpret_cast<uint8_t*>(q.d_kfs + (id - c->tmpl_kf)) + offsetof(KfDev, tmpl), c->h_null,
-                                   sizeof(void*), hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(q.d_kfs + id, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    // (the record reaches the device inside the KfInitArgs block: no copy per keyframe)
     return SVO_OK;
 }
 
@@ -683,8 +679,6 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
                 c->seqs[s].tmpl_base = base + (size_t)s * K * c->tmpl_block_bytes;
                 c->seqs[s].tmpl_valid = vbase + (size_t)s * K * c->tmpl_valid_bytes;
             }
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_null), 64, hipHostMallocDefault));
-            std::memset(c->h_null, 0, 64);
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -705,7 +699,6 @@ static int grp_destroy(svo_group* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_args) (void)hipHostFree(c->h_args);
     if (c->h_res) (void)hipHostFree(c->h_res);   // one pinned block: results, counts, inside counters
-    if (c->h_null) (void)hipHostFree(c->h_null);
     for (int i = 0; i < 10; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     // ImageSet structs: owned by the free lists, the current/previous pointers and keyframes
@@ -779,7 +772,10 @@ static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool fi
         ia->disparity = q.disparity; ia->frame_pose = c->d_res[s].pose_refined;
         ia->first_frame = first_frame ? 1 : 0; ia->new_kf_id = id; ia->kfs = q.d_kfs;
         ia->color_lcg = q.color_lcg; ia->n_out = &c->d_res[s].kf_n;
-        HIP_TRY(hipMemsetAsync(q.n_det, 0, sizeof(int) * SVO_MAX_PYRAMID_LEVELS, c->stream));
+        ia->record = *args_at<KfDev>(c, c->off_kfdev, s);
+        ia->tmpl_valid_bytes = (int)c->tmpl_valid_bytes;
+        ia->evict_id = (c->tmpl_kf > 0 && id >= c->tmpl_kf) ? id - c->tmpl_kf : -1;
+        ca->zero = q.n_det; ca->zero_count = SVO_MAX_PYRAMID_LEVELS;      // (detection counters: cleared by the compaction kernel)
     }
     if (m == 0) return SVO_OK;
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, c->args_bytes, hipMemcpyHostToDevice, c->stream));

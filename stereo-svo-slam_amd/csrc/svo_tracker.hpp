@@ -30,6 +30,8 @@ struct CompactArgs {
     int mode;          // 0: remove_outliers, 1: find_bad_keypoints
     int width, height;
     const int* enable; // optional device predicate
+    int* zero;         // optional: zero_count ints set to 0 (the detection counters of the keyframe that follows)
+    int zero_count;
 };
 void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t stream);
 
@@ -79,6 +81,11 @@ struct KfInitArgs {
     uint32_t* color_lcg;
     int* n_out;
     const int* enable;
+    // the record of the new keyframe (written to kfs[new_kf_id] by the kernel: no copy of its own per keyframe),
+    // the "stored" flags of its template cache block (cleared here) and the keyframe that loses the block (-1: none)
+    KfDev record;
+    int tmpl_valid_bytes;
+    int evict_id;
 };
 void launch_kf_init(const KfInitArgs* d_args, int batch, hipStream_t stream);
 
