@@ -117,22 +117,30 @@ constexpr int DET_RW = DET_MAX_CW + 2, DET_RH = DET_MAX_CH + 2;   // raw scores:
 __constant__ int c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 __constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
-// cv::FAST TYPE_9_16: corner test + cornerScore<16> (OpenCV fast.cpp / fast_score.cpp)
-__device__ inline int fast_score(const uint8_t* p, int stride, int threshold) {
-    int d[25];
+// cv::FAST TYPE_9_16 (OpenCV fast.cpp / fast_score.cpp) in two steps: the corner test (9 contiguous ring
+// pixels darker or brighter than the centre by more than the threshold) on every pixel, and
+// cornerScore<16> on the corners only (kf_detect_kernel gathers them first: the score is 2/3 of the work
+// and most pixels are no corners, but nearly every wavefront holds one)
+__device__ inline bool fast_is_corner(const uint8_t* p, int stride, int threshold) {
     const int v = p[0];
+    int d[16];
 #pragma unroll
-    for (int k = 0; k < 25; k++) d[k] = v - (int)p[c_ring_dy[k & 15] * stride + c_ring_dx[k & 15]];
-    // corner test: 9 contiguous darker (d > t) or brighter (d < -t) ring pixels
+    for (int k = 0; k < 16; k++) d[k] = v - (int)p[c_ring_dy[k] * stride + c_ring_dx[k]];
     bool corner = false;
     int cd = 0, cb = 0;
 #pragma unroll
     for (int k = 0; k < 25; k++) {
-        cd = (d[k] > threshold) ? cd + 1 : 0;
-        cb = (d[k] < -threshold) ? cb + 1 : 0;
+        cd = (d[k & 15] > threshold) ? cd + 1 : 0;
+        cb = (d[k & 15] < -threshold) ? cb + 1 : 0;
         corner = corner || cd > 8 || cb > 8;
     }
-    if (!corner) return 0;
+    return corner;
+}
+__device__ inline int fast_corner_score(const uint8_t* p, int stride, int threshold) {
+    int d[25];
+    const int v = p[0];
+#pragma unroll
+    for (int k = 0; k < 25; k++) d[k] = v - (int)p[c_ring_dy[k & 15] * stride + c_ring_dx[k & 15]];
     int a0 = threshold;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
@@ -157,6 +165,8 @@ __device__ inline int fast_score(const uint8_t* p, int stride, int threshold) {
     return -b0 - 1;
 }
 
+constexpr int DET_LIST = 2048;    // corners of a cell kept for the score pass (more: scored where they are found)
+
 __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __restrict__ args) {
     const DetectArgs& a = args[blockIdx.z];
     if (a.enable && !*G(a.enable)) return;
@@ -175,6 +185,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     __shared__ uint8_t s_t[DET_TH * DET_TW];
     __shared__ uint8_t s_raw[DET_RH * DET_RW];
     __shared__ unsigned s_key[4];
+    __shared__ uint16_t s_list[DET_LIST];
+    __shared__ int s_nlist;
 
     const int tw = gw + 8, th = gh + 8;
     for (int i = tid; i < tw * th; i += 256) {
@@ -183,15 +195,31 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
         s_t[r * DET_TW + c] = im.g()[(size_t)gy * im.stride + gx];
     }
     __syncthreads();
-    // raw FAST scores on the cell + 1 px (0 outside the detector's 3 px border)
+    // raw FAST scores on the cell + 1 px (0 outside the detector's 3 px border): corner test everywhere,
+    // the corners gathered in LDS, their scores computed by all lanes together
     const int rw = gw + 2, rh = gh + 2;
+    if (tid == 0) s_nlist = 0;
+    __syncthreads();
     for (int i = tid; i < rw * rh; i += 256) {
         const int r = i / rw, c = i % rw;
         const int gy = top - 1 + r, gx = left - 1 + c;
         int sc = 0;
-        if (gx >= 3 && gx < im.w - 3 && gy >= 3 && gy < im.h - 3)
-            sc = fast_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+        if (gx >= 3 && gx < im.w - 3 && gy >= 3 && gy < im.h - 3 &&
+            fast_is_corner(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6)) {
+            const int slot = atomicAdd(&s_nlist, 1);
+            if (slot < DET_LIST) s_list[slot] = (uint16_t)i;
+            else sc = fast_corner_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+        }
         s_raw[r * DET_RW + c] = (uint8_t)sc;
+    }
+    __syncthreads();
+    {
+        const int nl = min(s_nlist, DET_LIST);
+        for (int q = tid; q < nl; q += 256) {
+            const int i = s_list[q];
+            const int r = i / rw, c = i % rw;
+            s_raw[r * DET_RW + c] = (uint8_t)fast_corner_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+        }
     }
     __syncthreads();
     // NMS + first-best in row-major order
