@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
         int slot = 0;
         for (int task = wave; task < n_jb * n_mb && slot < SSD_SLOTS; task += SSD_THREADS / 64, slot++) {
             task_of[slot] = task;
-            const int mb = task / n_jb, jb = task - mb * n_jb;
+            const int mb = task >= n_jb ? 1 : 0, jb = task - mb * n_jb;      // (at most two row blocks: the map has <= 17 rows)
             // B: bytes [16 + 16 fh - fm, +16) of the padded template row
             const int o = 16 + 16 * fh - fm;
             const uint32_t* tb = reinterpret_cast<const uint32_t*>(s_t) + (o >> 2);
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     // the place of the search region, which nobody reads after the barrier above (17.4 KB of LDS per
     // workgroup instead of 21.7: one more workgroup fits beside the alignment kernel's on a CU)
     static_assert(sizeof(int) * SSD_MAX_MATCH <= SSD_R_ROWS * SSD_R_STRIDE, "match map must fit the region tile");
+    static_assert(SSD_MAX_MH <= 32, "two row blocks of 16 at most");
     int* const s_m = reinterpret_cast<int*>(s_r);
     {
         const int seg_len = (mw + 7) >> 3;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
         for (int slot = 0; slot < SSD_SLOTS; slot++) {
             const int task = task_of[slot];
             if (task < 0) continue;
-            const int mb = task / n_jb, jb = task - mb * n_jb;
+            const int mb = task >= n_jb ? 1 : 0, jb = task - mb * n_jb;      // (at most two row blocks: the map has <= 17 rows)
             const int j = 16 * jb + fm;                     // C/D: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
             for (int i = 0; i < 4; i++) {

@@ -285,13 +285,10 @@ bool launch_reproj(const ReprojArgs* d_args, int batch, int n_bound, hipStream_t
     const int cap = (std::max(n_bound, 1) + T - 1) / T * T;          // whole staging steps
     const size_t lds = (size_t)cap * 6 * sizeof(float);
     if (lds > 120 * 1024) return false;
-    static std::once_flag configured;
-    std::call_once(configured, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reproj_gn_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    });
+    static LdsLimit limit1, limit4;
+    if (raise_lds_limit(limit1, reinterpret_cast<const void*>(reproj_gn_kernel<1>), 120 * 1024) != hipSuccess ||
+        raise_lds_limit(limit4, reinterpret_cast<const void*>(reproj_gn_kernel<4>), 120 * 1024) != hipSuccess)
+        return false;
     if (T == 64)
         hipLaunchKernelGGL(reproj_gn_kernel<1>, dim3(batch), dim3(64), lds, stream, d_args, cap);
     else

@@ -808,14 +808,12 @@ static int sia_img_bytes(const svo_camera_settings& cam, int width, int height) 
 }
 
 template <int WAVES, int MODE>
-static void sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap, size_t lds, hipStream_t stream) {
-    // (call_once: a second group's thread must not launch before the first has raised the limit)
-    static std::once_flag configured;
-    std::call_once(configured, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sia_gn_kernel<WAVES, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SIA_LDS_BUDGET);
-    });
+static bool sia_launch_shape(const SiaArgs* d_args, int batch, int img, int cap, size_t lds, hipStream_t stream) {
+    static LdsLimit limit;
+    if (raise_lds_limit(limit, reinterpret_cast<const void*>(sia_gn_kernel<WAVES, MODE>), (int)SIA_LDS_BUDGET) != hipSuccess)
+        return false;
     hipLaunchKernelGGL((sia_gn_kernel<WAVES, MODE>), dim3(batch), dim3(64 * WAVES), lds, stream, d_args, img, cap);
+    return true;
 }
 
 // Workgroup shape of a launch: `batch` sequences of at most n_bound keypoints, one keypoint per
@@ -860,7 +858,7 @@ bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam
     }
     if (lds > SIA_LDS_BUDGET || cap > rec_cap) return false;
     hipLaunchKernelGGL(sia_prep_kernel, dim3((((nb + 3) & ~3) * 16 + 63) / 64, n_lv, batch), dim3(64), 0, stream, d_args);
-#define SIA_CASE(W, M) if (waves == W && mode == M) { sia_launch_shape<W, M>(d_args, batch, img, cap, lds, stream); return true; }
+#define SIA_CASE(W, M) if (waves == W && mode == M) return sia_launch_shape<W, M>(d_args, batch, img, cap, lds, stream);
     SIA_CASE(1, 0) SIA_CASE(2, 0) SIA_CASE(4, 0)
     SIA_CASE(1, 1) SIA_CASE(2, 1) SIA_CASE(4, 1)
     SIA_CASE(1, 2) SIA_CASE(2, 2) SIA_CASE(4, 2)

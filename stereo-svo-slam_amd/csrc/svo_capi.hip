@@ -265,8 +265,10 @@ extern "C" int svo_sparse_align(svo_handle* h, const svo_image* prev_pyr, const 
     SiaArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
-    if (!launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->rec_cap, h->exact_pinv, h->stream))
+    if (!launch_sia(d, 1, *cam, cur_pyr[0].width, cur_pyr[0].height, n, h->rec_cap, h->exact_pinv, h->stream)) {
+        HIP_TRY(hipGetLastError());          // (the LDS limit of the kernel could not be raised on this device)
         return fail(SVO_ERR_CAPACITY, "svo_sparse_align: %d keypoints exceed the workspaces", n);
+    }
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -322,8 +324,10 @@ extern "C" int svo_reproj_gn(svo_handle* h, svo_kp2d* kps2d, const svo_kp3d* kps
     ReprojArgs* d;
     rc = stage(h, ra, &d);
     if (rc) return rc;
-    if (!launch_reproj(d, 1, n, h->stream))
+    if (!launch_reproj(d, 1, n, h->stream)) {
+        HIP_TRY(hipGetLastError());
         return fail(SVO_ERR_CAPACITY, "svo_reproj_gn: %d keypoints do not fit LDS", n);
+    }
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

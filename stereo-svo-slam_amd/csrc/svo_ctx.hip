@@ -972,15 +972,19 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         int grid_n = 1;
         for (int j = 0; j < M; j++) grid_n = std::max(grid_n, c->seqs[act[j]].n_host);
         grid_n = std::min(grid_n, c->cap);
-        if (!launch_sia(dargs_at<SiaArgs>(c, c->off_sia), M, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream))
+        if (!launch_sia(dargs_at<SiaArgs>(c, c->off_sia), M, c->cam, c->width, c->height, grid_n, c->rec_cap, c->exact_pinv, c->stream)) {
+            HIP_TRY(hipGetLastError());      // (the LDS limit of the kernel could not be raised on this device)
             return svo_set_error(SVO_ERR_CAPACITY, "sparse alignment: %d keypoints exceed the workspaces", grid_n);
+        }
         HIP_TRY(hipGetLastError());
         SVO_MARK(3);
         launch_klt(dargs_at<KltArgs>(c, c->off_klt), M, grid_n, c->cam.window_size_opt_flow, c->stream);
         HIP_TRY(hipGetLastError());
         SVO_MARK(4);
-        if (!launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), M, grid_n, c->stream))
+        if (!launch_reproj(dargs_at<ReprojArgs>(c, c->off_rp), M, grid_n, c->stream)) {
+            HIP_TRY(hipGetLastError());
             return svo_set_error(SVO_ERR_CAPACITY, "reprojection GN: %d keypoints do not fit LDS", grid_n);
+        }
         HIP_TRY(hipGetLastError());
         SVO_MARK(5);
         launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->stream);

@@ -6,10 +6,30 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include "svo_device.hpp"
 
 namespace svo {
+
+// A kernel's dynamic-LDS limit belongs to the device that is current when it is raised: once per
+// device and kernel (a second sequence group's thread must not launch before the first has raised it).
+// Returns the HIP error of the attribute call, so a failure surfaces at the launch that needs it.
+constexpr int SVO_MAX_DEVICES = 64;
+struct LdsLimit {
+    std::once_flag once[SVO_MAX_DEVICES];
+    hipError_t err[SVO_MAX_DEVICES];
+};
+inline hipError_t raise_lds_limit(LdsLimit& st, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= SVO_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::call_once(st.once[dev], [&st, dev, kernel, bytes] {
+        st.err[dev] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    });
+    return st.err[dev];
+}
 
 // ---------------------------------------------------------------- pyramids
 struct PyrArgs {
@@ -51,7 +71,8 @@ struct SiaArgs {
     PoseMats* mats_out;           // optional: rotation matrices of pose_out, for the kernels that project with it
 };
 // n_bound: upper bound of the keypoint counts of the launch's sequences (chooses the workgroup
-// shape); rec_cap: SiaArgs::rec_cap of every block; exact: the value of SiaArgs::exact_pinv in every block (sizes the LDS staging)
+// shape); rec_cap: SiaArgs::rec_cap of every block; exact: the value of SiaArgs::exact_pinv in every block (sizes the LDS staging).
+// false: capacity, or the LDS limit could not be raised (then hipGetLastError() reports it)
 bool launch_sia(const SiaArgs* d_args, int batch, const svo_camera_settings& cam, int width,
                 int height, int n_bound, int rec_cap, int exact, hipStream_t stream);   // false: capacity
 size_t sia_rec_ws_floats(const svo_camera_settings& cam, int rec_cap);   // size of SiaArgs::rec_ws
