@@ -233,21 +233,25 @@ def test_loop_trajectory_is_closed_and_smooth():
     assert np.allclose(step[-1], np.abs(p[0] - p[-1]))
 
 
-def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path):
-    """profiles/r02_pmc.json (read by bench.py for roofline.binding_roof) is what
+@pytest.mark.parametrize("rnd", ["r02", "r03"])
+def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path, rnd):
+    """profiles/r0N_pmc.json (r03: read by bench.py for roofline.binding_roof and valu_issue) is what
     tools/make_pmc_json.py derives from the committed counter and kernel-stats CSVs."""
     import json, shutil, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
     for name in ("pmc_sq.csv", "kernel_stats.csv", "pmc.json"):
-        shutil.copy(os.path.join(prof, "r02_" + name), tmp_path / name)
+        shutil.copy(os.path.join(prof, rnd + "_" + name), tmp_path / name)
     out = tmp_path / "out"
     out.mkdir()
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_pmc_json.py"), str(tmp_path), str(out),
                            "reclassify"], stdout=subprocess.DEVNULL)
     new = json.load(open(out / "pmc.json"))
-    old = json.load(open(os.path.join(prof, "r02_pmc.json")))
+    old = json.load(open(os.path.join(prof, rnd + "_pmc.json")))
     assert new["seqs"] == old["seqs"] == 2048 and new["groups"] == old["groups"] == 8
+    if rnd == "r03":      # the chip-level figure bench.py prints: VALU instructions per tracked frame
+        assert abs(new["valu_instructions_per_frame"] - old["valu_instructions_per_frame"]) < 1.0
+        assert 1.5e6 < new["valu_instructions_per_frame"] < 2.5e6
     assert set(new["kernels"]) == set(old["kernels"]) and "sia_gn_kernel" in new["kernels"]
     for k, v in new["kernels"].items():
         assert v["bound"] == old["kernels"][k]["bound"]
