@@ -34,6 +34,26 @@ __device__ inline uint32_t load_u8x4(const ImgView& im, int y, int x, int valid)
     return v;
 }
 
+// 16 consecutive pixels of row y starting at column x (any alignment), every valid byte ^ (flip & 0xff),
+// bytes from `valid` on = (pad & 0xff): one 16-byte load when the row has them, dwords otherwise
+__device__ inline uint4 load_u8x16(const ImgView& im, int y, int x, int valid, uint32_t flip, uint32_t pad) {
+    uint32_t w[4];
+    if (x + 16 <= im.w) {
+        const uint8_t* src = im.g() + (size_t)y * im.stride + x;
+        __builtin_memcpy(w, src, 16);                     // (one global_load_dwordx4: any byte alignment)
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = load_u8x4(im, y, x + 4 * k, 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int nv = valid - 4 * k;                     // valid bytes of this dword
+        const uint32_t vm = nv >= 4 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+        w[k] = ((w[k] ^ flip) & vm) | (pad & ~vm);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 constexpr int SSD_MAX_WIN = 35;                 // template edge
 constexpr int SSD_MAX_MH = 17, SSD_MAX_MW = 65; // match map: (2*search_y+1) x (search_x+1)
 constexpr int SSD_T_STRIDE = 96;                // bytes per padded template row: 16 zeros | row | zeros
@@ -106,24 +126,22 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
         return;
     }
 
-    // ---- stage: template rows as [16 zero bytes | row ^ 0x80 | zeros], search region ^ 0x80
-    for (int i = tid; i < (SSD_MAX_WIN + 1) * (SSD_T_STRIDE / 4); i += SSD_THREADS) {
-        const int r = i / (SSD_T_STRIDE / 4), d = i % (SSD_T_STRIDE / 4);
-        const int c = 4 * (d - 4);                        // template column of the dword's first byte
-        uint32_t v = 0;
-        if (r < th && c >= 0 && c < tw) {
-            const int valid = tw - c;
-            const uint32_t vm = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
-            v = load_u8x4(a.left, y11 + r, x11 + c, valid) ^ (0x80808080u & vm);
-        }
-        reinterpret_cast<uint32_t*>(s_t)[i] = v;
+    // ---- stage: template rows as [16 zero bytes | row ^ 0x80 | zeros], search region ^ 0x80 (bytes past
+    // the region's width: 0x80), 16 bytes per lane and step: a template row is three chunks, a region row
+    // up to six (round 2 staged dwords: 7 + 3 trips of ~22 instructions per thread against 2 + 1 here)
+    static_assert(SSD_T_STRIDE % 16 == 0 && SSD_R_STRIDE % 16 == 0, "rows are whole 16-byte chunks");
+    for (int i = tid; i < (SSD_MAX_WIN + 1) * (SSD_T_STRIDE / 16); i += SSD_THREADS) {
+        const int r = i / (SSD_T_STRIDE / 16), ch = i % (SSD_T_STRIDE / 16);
+        const int c = 16 * (ch - 1);                      // template column of the chunk's first byte
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < th && c >= 0 && c < tw) v = load_u8x16(a.left, y11 + r, x11 + c, tw - c, 0x80808080u, 0u);
+        reinterpret_cast<uint4*>(s_t)[i] = v;
     }
-    for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 4); i += SSD_THREADS) {
-        const int r = i / (SSD_R_STRIDE / 4), d = i % (SSD_R_STRIDE / 4);
-        uint32_t v = 0;
-        if (r < rh && 4 * d < rw)
-            v = load_u8x4(a.right, y21 + r, x21 + 4 * d, rw - 4 * d) ^ 0x80808080u;
-        reinterpret_cast<uint32_t*>(s_r)[i] = v;
+    for (int i = tid; i < SSD_R_ROWS * (SSD_R_STRIDE / 16); i += SSD_THREADS) {
+        const int r = i / (SSD_R_STRIDE / 16), ch = i % (SSD_R_STRIDE / 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < rh && 16 * ch < rw) v = load_u8x16(a.right, y21 + r, x21 + 16 * ch, rw - 16 * ch, 0x80808080u, 0x80808080u);
+        reinterpret_cast<uint4*>(s_r)[i] = v;
     }
     __syncthreads();
 

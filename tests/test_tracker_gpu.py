@@ -323,6 +323,30 @@ def test_failure_in_one_group_latches_the_ctx(monkeypatch):
     ctx.close()
 
 
+def test_klt_template_cache_changes_nothing(monkeypatch):
+    """The KLT template cache (a keyframe's templates kept in HBM for the sequence's last keyframes)
+    only replaces recomputation by a load: with the cache off, with a ring of one keyframe (every
+    new keyframe evicts the previous one, whose points are tracked from the images again) and with
+    the default ring of four, every frame of a sequence with several keyframes is the same."""
+    n_frames = 36
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", n_frames, 2, device="cpu", motion_scale=4.0)
+    runs = {}
+    for k in ("0", "1", "4"):
+        monkeypatch.setenv("SVO_KLT_CACHE_KF", k)
+        ctx = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1)
+        frames = []
+        for i in range(n_frames):
+            ctx.new_images([L[i].numpy()], [R[i].numpy()], [float(ts[i])])
+            f = ctx.get_frame(0)
+            frames.append((f.pose.copy(), f.kps2d.copy(), f.kps3d.copy(), f.info.copy()))
+        runs[k] = (frames, ctx.num_keyframes(0))
+        ctx.close()
+    assert runs["0"][1] == runs["1"][1] == runs["4"][1] >= 3
+    for k in ("1", "4"):
+        for i, (a, b) in enumerate(zip(runs["0"][0], runs[k][0])):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (k, i)
+
+
 def test_update_pose_matches_oracle():
     cfg = dict(synth.CONFIGS["tiny"])
     gpu = StereoSlamBatch(cfg, cfg["width"], cfg["height"], 1)
