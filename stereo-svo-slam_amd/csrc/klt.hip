@@ -4,22 +4,22 @@
 // tracking every keypoint from the Gaussian pyramid of its ORIGIN KEYFRAME
 // into the current frame (PoseRefiner::refine_pose, src/lib/pose_refinement.cpp:72-118).
 //
-// One workgroup per keypoint, all pyramid levels and iterations inside the
+// One wavefront per keypoint, all pyramid levels and iterations inside the
 // kernel. A thread owns one window column and RPT consecutive rows, so
-//  * the bilinear taps slide down the rows: one unaligned 16-bit LDS read per
-//    row, and every 4-tap interpolation is two v_dot2_i32_i16 (14-bit weights
-//    and pixels / derivatives all fit int16);
+//  * the bilinear taps slide down the rows, and every 4-tap interpolation is
+//    two v_dot2_i32_i16 (14-bit weights and pixels / derivatives all fit int16);
 //  * the fixed-point template (I, Ix, Iy; 5 fractional bits) of the thread's
-//    rows lives in REGISTERS as int16 row pairs for all iterations of a level:
-//    the mismatch vector is v_pk_sub_i16 + v_dot2 per row pair.
-// Per level the (w+3)^2 neighbourhood of the reference point and a search
-// tile with a 6 px margin are staged in LDS — dword loads when the tile lies
-// inside the image, BORDER_REFLECT_101 byte addressing otherwise — and the
-// Scharr derivatives of OpenCV's pyramid are computed from the LDS tile (zero
-// outside the image, the constant border of cv::buildOpticalFlowPyramid).
-// An iteration touches HBM only when the window drifts out of the search
-// tile. All window sums are exact integers, so the result does not depend on
-// the reduction order.
+//    rows lives in REGISTERS as int16 row pairs for all iterations of a level;
+//    b = sum (J - I) dI is evaluated as sum J dI minus the level's constant sum I dI.
+// The template depends on the keyframe only: a tracker builds it once per
+// keypoint and level (reference neighbourhood staged in LDS, Scharr derivatives
+// of OpenCV's pyramid computed from the tile: zero outside the image, the
+// constant border of cv::buildOpticalFlowPyramid) and keeps it in HBM
+// (KfDev::tmpl); later frames load it. The search tile of the current frame is
+// staged per level as 16-bit values in two copies one pixel apart, so that a
+// bilinear pair is one aligned ds_read_b32. An iteration touches HBM only when
+// the window drifts out of the search tile. All window sums are exact integers,
+// so the result does not depend on the reduction order.
 #include "svo_kernels.hpp"
 #include <utility>
 

@@ -25,8 +25,9 @@
 //     (:112-117; v_readlane adds for one wave, an LDS pass otherwise): the stop test |dcost| < 1
 //     is exact. The normal equations have two forms: the DEFAULT accumulates hessian += row^T row
 //     and residual -= row * diff row by row in storage order (:399-403, :472-477) — 64 keypoints
-//     stage their rows in LDS, 27 accumulator lanes walk them, four keypoints per trip — and
-//     inverts by the Jacobi SVD, so the whole iteration trace is the reference's; the fast solver
+//     stage their rows in LDS, 27 accumulator lanes walk them, four keypoints per trip (with four
+//     waves: wave 0 only adds while the others compute and stage the next keypoints, two buffers) —
+//     and inverts by the Jacobi SVD, so the whole iteration trace is the reference's; the fast solver
 //     (svo_*_set_fast_solver) builds sum_kp J^T (sum_px g g^T) J with a wave reduction and solves
 //     by LDL^T.
 #include "svo_kernels.hpp"
