@@ -413,6 +413,10 @@ def main():
                 "peak_wave_instructions_per_s": VALU_PEAK,
                 "source": f"instructions per frame from profiles/{PMC_PROFILE} (replayed), frames/s measured in this run"}
 
+    issue = None
+    if same_cfg(pmc) and pmc.get("issue_activity"):
+        issue = dict(pmc["issue_activity"], source=f"profiles/{PMC_PROFILE}: sum of SQ_ACTIVE_INST_ANY over the kernels of a step x 4 / "
+                                                    "(step time x 2.4 GHz x 1024 SIMDs), an earlier counter run of this command (replayed)")
     sample, sample_groups = group_sample(B, G)
     gpu_traj = {s: np.asarray(slam.get_trajectory(s)) for s in sample}
     # fps over tracked (non-keyframe) frames: the keyframe kernels' share of the groups' event time taken out
@@ -510,6 +514,7 @@ def main():
         "parity_max_abs_pose_diff": cpu and cpu["parity"] and cpu["parity"]["max_abs_pose_diff"],
         "parity_sequences_compared": cpu and cpu["parity"] and cpu["parity"]["sequences_compared"],
         "valu_issue_frac_of_step": valu and valu["frac"],
+        "issue_active_frac_of_step": issue and issue["per_simd_cycle"],
         "c3_fps": c3 and c3["frames_per_s"], "c3_pyramids_hbm_frac": c3 and c3["pyramids_hbm_frac"],
         "setup_s": t_setup, "wall_s": time.perf_counter() - t_start,
         "config": {"workload": f"{args.config}: {WORKLOAD_LABEL.get(args.config, 'synthetic')} {cfg['width']}x{cfg['height']} stereo, "
@@ -536,7 +541,7 @@ def main():
                    "single_sequence": single, "host_input": host_input, "c3": c3,
                    "host_cpus": os.cpu_count(), "usable_cpus": usable_cpus(),
                    "summaries_gathered": int(summaries.shape[0])},
-        "roofline": roofline, "valu_issue": valu, "cpu_baseline": cpu,
+        "roofline": roofline, "valu_issue": valu, "issue_activity": issue, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
 

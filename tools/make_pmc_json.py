@@ -53,6 +53,20 @@ def valu_per_frame(sq, calls, seqs_per_launch):
     return total / (steps * seqs_per_launch)
 
 
+def issue_activity(sq, calls, groups, ms_per_step):
+    """Sum over all kernels of SQ_ACTIVE_INST_ANY (quad-cycles in which a wave issues an instruction of any kind)
+    of one step x 4 / (step time x clock x SIMDs): how much of the chip's instruction issue the step uses,
+    and every kernel's share of it."""
+    steps = calls.get("sia_gn_kernel", 0.0) / max(groups, 1)
+    if steps <= 0 or ms_per_step <= 0:
+        return None
+    per = {k: c.get("SQ_ACTIVE_INST_ANY", 0.0) * calls.get(k, 0.0) / steps for k, c in sq.items() if k in calls}
+    tot = sum(per.values())
+    return {"per_simd_cycle": tot * 4 / (ms_per_step * 1e-3 * CLK * N_SIMD),
+            "share": {k: v / tot for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if tot > 0 and v / tot >= 0.005},
+            "ms_per_step": ms_per_step}
+
+
 SERIAL = ("sia_gn_kernel", "reproj_gn_kernel")     # one or a few waves per sequence, a serial chain
 
 
@@ -95,6 +109,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "reclassify":
     old = json.load(open(f"{src}/pmc.json"))
     old["kernels"] = classify(sq, weighted_durations(f"{src}/kernel_stats.csv"))
     old["valu_instructions_per_frame"] = valu_per_frame(sq, call_counts(f"{src}/kernel_stats.csv"), old["seqs"] / old["groups"])
+    if old.get("issue_activity"):
+        old["issue_activity"] = issue_activity(sq, call_counts(f"{src}/kernel_stats.csv"), old["groups"], old["issue_activity"]["ms_per_step"])
     json.dump(old, open(f"{out}/pmc.json", "w"), indent=1)
     print(json.dumps({k: {"bound": v["bound"], "frac": round(v["frac"], 4)} for k, v in old["kernels"].items()}, indent=1))
     sys.exit(0)
@@ -112,6 +128,7 @@ cfg = bench["config"]
 meta = {"config": bench["config"]["workload"].split(":")[0], "seqs": cfg["sequences_per_gpu"], "groups": cfg["sequence_groups"]}
 json.dump({**meta, "kernels": kernels,
            "valu_instructions_per_frame": valu_per_frame(sq, call_counts(f"{out}/kernel_stats.csv"), meta["seqs"] / meta["groups"]),
+           "issue_activity": issue_activity(sq, call_counts(f"{out}/kernel_stats.csv"), meta["groups"], bench["ms_per_step"]),
            "note": "rocprofv3 --pmc SQ_* pass of the default bench command (own run, kernel-include-regex svo); "
                    "durations from the --kernel-trace --stats run of the same command"},
           open(f"{out}/pmc.json", "w"), indent=1)
