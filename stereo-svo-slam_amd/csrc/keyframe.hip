@@ -165,6 +165,17 @@ __device__ inline int fast_corner_score(const uint8_t* p, int stride, int thresh
     return -b0 - 1;
 }
 
+// i / d for 0 <= i < 2^13 and 4 <= d <= 128 without an integer division per element (a runtime
+// divisor costs ~30 VALU instructions; the loops below divide every pixel index): exact while
+// i * (d - 1) < 2^20
+struct SmallDiv {
+    unsigned m;
+    int d;
+    __device__ explicit SmallDiv(int d_) : m(((1u << 20) + (unsigned)d_ - 1u) / (unsigned)d_), d(d_) {}
+    __device__ int quot(int i) const { return (int)(((unsigned)i * m) >> 20); }
+    __device__ void divmod(int i, int& q, int& r) const { q = quot(i); r = i - q * d; }
+};
+
 constexpr int DET_LIST = 2048;    // corners of a cell kept for the score pass (more: scored where they are found)
 
 __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __restrict__ args) {
@@ -189,8 +200,10 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     __shared__ int s_nlist;
 
     const int tw = gw + 8, th = gh + 8;
+    const SmallDiv div_tw(tw), div_rw(gw + 2), div_gw(gw), div_gh(gh);
     for (int i = tid; i < tw * th; i += 256) {
-        const int r = i / tw, c = i % tw;
+        int r, c;
+        div_tw.divmod(i, r, c);
         const int gy = reflect101(top - 4 + r, im.h), gx = reflect101(left - 4 + c, im.w);
         s_t[r * DET_TW + c] = im.g()[(size_t)gy * im.stride + gx];
     }
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     if (tid == 0) s_nlist = 0;
     __syncthreads();
     for (int i = tid; i < rw * rh; i += 256) {
-        const int r = i / rw, c = i % rw;
+        int r, c;
+        div_rw.divmod(i, r, c);
         const int gy = top - 1 + r, gx = left - 1 + c;
         int sc = 0;
         if (gx >= 3 && gx < im.w - 3 && gy >= 3 && gy < im.h - 3 &&
@@ -217,7 +231,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
         const int nl = min(s_nlist, DET_LIST);
         for (int q = tid; q < nl; q += 256) {
             const int i = s_list[q];
-            const int r = i / rw, c = i % rw;
+            int r, c;
+            div_rw.divmod(i, r, c);
             s_raw[r * DET_RW + c] = (uint8_t)fast_corner_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
         }
     }
@@ -225,7 +240,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     // NMS + first-best in row-major order
     unsigned best = 0;
     for (int i = tid; i < gw * gh; i += 256) {
-        const int r = i / gw, c = i % gw;
+        int r, c;
+        div_gw.divmod(i, r, c);
         if (top + r >= im.h) continue;
         const uint8_t* q = &s_raw[(r + 1) * DET_RW + c + 1];
         const int sc = q[0];
@@ -252,7 +268,8 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
         __syncthreads();
         unsigned eb = 0;
         for (int i = tid; i < gw * gh; i += 256) {
-            const int c = i / gh, r = i % gh;        // order index = x*gh + y
+            int c, r;
+            div_gh.divmod(i, c, r);                  // order index = x*gh + y
             const uint8_t* p1 = &s_t[(r + 4) * DET_TW + c + 4];
             const uint8_t* p0 = p1 - DET_TW;
             const uint8_t* p2 = p1 + DET_TW;
