@@ -25,24 +25,38 @@
 
 namespace svo {
 
-constexpr int KLT_MAX_WIN = 35;
-constexpr int KLT_MARGIN = 6;
-constexpr int KLT_DW = KLT_MAX_WIN + 1;                 // derivative / tap grid edge
-constexpr int KLT_RS = 44;                              // row stride of the reference tile: (w+3) + 3 alignment slack, /4
-constexpr int KLT_RROWS = KLT_MAX_WIN + 3;              // also >= 1 + rows covered by the row groups + 1
-constexpr int KLT_TJS = 52;                             // columns of the search tile: (w+1) + 2*margin + 3, /4 (<= 2 * KLT_J2S)
-constexpr int KLT_TJROWS = KLT_DW + 2 * KLT_MARGIN + 2;  // + slack: idle rows of the last row group are read, not used
+constexpr int KLT_MAX_WIN = 35;                        // (the entry points reject larger windows)
+static_assert(KLT_MAX_WIN + 1 <= 36, "largest kernel shape");
+#ifndef SVO_KLT_MARGIN
+#define SVO_KLT_MARGIN 6
+#endif
+constexpr int KLT_MARGIN = SVO_KLT_MARGIN;        // pixels the window may drift before the search tile is staged again
 // The search tile is kept as 16-bit values (pixel << 7) in TWO copies, the second shifted by one pixel:
 // the bilinear pair (p[x], p[x+1]) of any column x is then ONE aligned ds_read_b32 (copy x & 1, dword
 // x >> 1) that already is the int16 pair v_dot2 wants — no byte loads, no packing in the iteration.
 // (Unaligned ds_read_b32 stall the LDS pipeline: SQ_LDS_UNALIGNED_STALL.) The << 7 turns the
 // (sum + 2^8) >> 9 of the fixed-point interpolation into a >> 16: the two results of a row pair are
-// the high halves of two dwords, one v_perm_b32. Row stride 27 dwords (16 rows = 48 banks on) and the
+// the high halves of two dwords, one v_perm_b32. Odd row stride (16 rows = 16 or 48 banks on) and the
 // second copy 32 banks away from the first: the 32 columns x 2 row groups of a window read hit 64
 // different banks.
-constexpr int KLT_J2S = 27;                             // dwords per tile row of one copy (54 pixels >= KLT_TJS)
-constexpr int KLT_J2COPY = ((KLT_TJROWS * KLT_J2S + 63) / 64) * 64 + 32;   // dwords between the two copies
-static_assert(KLT_TJS <= 2 * KLT_J2S, "search tile row");
+// Sizes per kernel shape (CW = 32: windows up to 31, CW = 36: up to 35). The LDS of a workgroup is what
+// bounds the wavefronts per CU of this kernel (125 registers: 16), so the 32-column shape does not pay
+// for the 36-column one: 9.3 KB instead of 12.8 (12 -> 16 wavefronts per CU).
+template <int CW>
+struct KltGeom {
+    static constexpr int DW = CW;                            // derivative / tap grid edge (w+1 <= CW)
+    static constexpr int RS = 44;                            // row stride of the reference tile: (w+3) + 3 alignment slack, /4
+    static constexpr int RROWS = CW + 2;                     // w+3 rows; also >= 1 + rows covered by the row groups + 1
+    static constexpr int TJROWS = DW + 2 * KLT_MARGIN + 2;   // + slack: idle rows of the last row group are read, not used
+    static constexpr int TJS = (DW + 2 * KLT_MARGIN + 6) & ~3;   // columns of the search tile: (w+1) + 2*margin + 3, /4
+    static constexpr int J2S = (TJS / 2) | 1;                // dwords per tile row of one copy
+    static constexpr int J2COPY = ((TJROWS * J2S + 63) / 64) * 64 + 32;   // dwords between the two copies
+    static constexpr int SD = (DW + 1) * DW;                 // ints of the derivative grid (+ one slack row)
+    static constexpr int SJ2 = J2COPY + TJROWS * J2S;        // dwords of the two-copy search tile
+    static constexpr int SI = (RROWS * RS + 3) / 4;          // dwords of the reference tile
+    static constexpr int LDS_DWORDS = SD + SI > SJ2 ? SD + SI : SJ2;
+    static_assert(TJS <= 2 * J2S, "search tile row");
+};
 #ifndef SVO_KLT_THREADS
 #define SVO_KLT_THREADS 64          // 128: two waves per keypoint (4 row groups of 8 rows)
 #endif
@@ -215,10 +229,12 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
 }
 
 // Search tile: rows [y0, y0+rows) x columns [x0, x0+4*nq) of `im` as (pixel << 7) 16-bit values in
-// two copies, copy 0 from column 0 and copy 1 from column 1 (KLT_J2S dwords per row, KLT_J2COPY
+// two copies, copy 0 from column 0 and copy 1 from column 1 (GEO::J2S dwords per row, GEO::J2COPY
 // dwords apart). Inside the image: one dword per lane, 16 lanes per row (a DPP row: the next
 // dword's first pixel comes from the neighbouring lane); else byte by byte with BORDER_REFLECT_101.
+template <class GEO>
 __device__ inline void stage_tile_j2(uint32_t* tile, const ImgView& im, int x0, int y0, int nq, int rows) {
+    constexpr int KLT_TJROWS = GEO::TJROWS, KLT_J2S = GEO::J2S, KLT_J2COPY = GEO::J2COPY;
     const int tid = threadIdx.x;
     const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * nq <= im.w && y0 + rows <= im.h &&
                       (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
@@ -273,8 +289,13 @@ __device__ inline void stage_tile_j2(uint32_t* tile, const ImgView& im, int x0, 
 // One wavefront per keypoint (KLT_THREADS = 64): no cross-wave barrier in the iteration, and a
 // single-wave workgroup finds a slot while the Gauss-Newton kernels of other sequence groups hold
 // most of a CU's registers (+3 % frames/s against 128 threads on the 768-sequence bench).
+#ifdef SVO_KLT_WAVES_PER_EU
+#define KLT_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_KLT_WAVES_PER_EU)))
+#else
+#define KLT_OCC_ATTR
+#endif
 template <int CW>
-__global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* __restrict__ args) {
+__global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(const KltArgs* __restrict__ args) {
     constexpr int NG = KLT_THREADS / CW;                               // row groups
     constexpr int ROWS = CW;                                            // tap rows to cover (w+1 <= CW)
     constexpr int RPT = (((ROWS + NG - 1) / NG) + 1) & ~1;              // even: rows are kept as pairs
@@ -290,13 +311,14 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
     const bool row_on = lr < NG;                 // CW = 36: the last 20 threads only help with the tiles
     const int y0 = row_on ? lr * RPT : 0;
 
-    __shared__ __attribute__((aligned(16))) uint8_t s_I[KLT_RROWS * KLT_RS];
-    // s_d: packed (dx, dy) int16 at the tap positions (+ one slack row), only alive while the template is
-    // built; the search tile (two 16-bit copies) takes the same LDS afterwards
-    constexpr int KLT_SD = (KLT_DW + 1) * KLT_DW, KLT_SJ2 = KLT_J2COPY + KLT_TJROWS * KLT_J2S;
-    __shared__ __attribute__((aligned(16))) int s_dj[KLT_SD > KLT_SJ2 ? KLT_SD : KLT_SJ2];
-    int* const s_d = s_dj;
-    uint32_t* const s_J2 = reinterpret_cast<uint32_t*>(s_dj);
+    // one LDS block: while the template is built, s_d (packed (dx, dy) int16 at the tap positions + one
+    // slack row) and behind it the reference tile s_I; afterwards the search tile (two 16-bit copies)
+    using GEO = KltGeom<CW>;
+    constexpr int KLT_DW = GEO::DW, KLT_RS = GEO::RS, KLT_RROWS = GEO::RROWS, KLT_J2S = GEO::J2S, KLT_J2COPY = GEO::J2COPY;
+    __shared__ __attribute__((aligned(16))) int s_mem[GEO::LDS_DWORDS];
+    int* const s_d = s_mem;
+    uint8_t* const s_I = reinterpret_cast<uint8_t*>(s_mem + GEO::SD);
+    uint32_t* const s_J2 = reinterpret_cast<uint32_t*>(s_mem);
     __shared__ double s_part[KLT_WAVES][8];
 
     // the keyframe record is wave-uniform: its fields are read where they are used. (A local copy of
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(KLT_THREADS) void klt_track_kernel(const KltArgs* _
         auto load_tile = [&](int cx, int cy) {
             tx0 = (cx - KLT_MARGIN) & ~3; ty0 = cy - KLT_MARGIN;
             __syncthreads();
-            stage_tile_j2(s_J2, J, tx0, ty0, TW >> 2, TJ);
+            stage_tile_j2<GEO>(s_J2, J, tx0, ty0, TW >> 2, TJ);
             __syncthreads();
             have_tile = true;
         };
