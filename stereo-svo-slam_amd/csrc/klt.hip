@@ -21,6 +21,7 @@
 // the window drifts out of the search tile. All window sums are exact integers,
 // so the result does not depend on the reduction order.
 #include "svo_kernels.hpp"
+#include <cstring>
 #include <utility>
 
 namespace svo {
@@ -36,9 +37,10 @@ constexpr int KLT_MARGIN = SVO_KLT_MARGIN;        // pixels the window may drift
 // x >> 1) that already is the int16 pair v_dot2 wants — no byte loads, no packing in the iteration.
 // (Unaligned ds_read_b32 stall the LDS pipeline: SQ_LDS_UNALIGNED_STALL.) The << 7 turns the
 // (sum + 2^8) >> 9 of the fixed-point interpolation into a >> 16: the two results of a row pair are
-// the high halves of two dwords, one v_perm_b32. Odd row stride (16 rows = 16 or 48 banks on) and the
-// second copy 32 banks away from the first: the 32 columns x 2 row groups of a window read hit 64
-// different banks.
+// the high halves of two dwords, one v_perm_b32. ds_read_b32 serves lanes 0-31 and 32-63 in one LDS
+// cycle each, banks = dword address mod 32: a row group's 32 columns read 16 consecutive dwords of either
+// copy, so the second copy lies 16 banks (mod 32) from the first. (Until round 3 it was 32 on: every window
+// read a two-way conflict.)
 // Sizes per kernel shape (CW = 32: windows up to 31, CW = 36: up to 35). The LDS of a workgroup is what
 // bounds the wavefronts per CU of this kernel (125 registers: 16), so the 32-column shape does not pay
 // for the 36-column one: 9.3 KB instead of 12.8 (12 -> 16 wavefronts per CU).
@@ -50,7 +52,7 @@ struct KltGeom {
     static constexpr int TJROWS = DW + 2 * KLT_MARGIN + 2;   // + slack: idle rows of the last row group are read, not used
     static constexpr int TJS = (DW + 2 * KLT_MARGIN + 6) & ~3;   // columns of the search tile: (w+1) + 2*margin + 3, /4
     static constexpr int J2S = (TJS / 2) | 1;                // dwords per tile row of one copy
-    static constexpr int J2COPY = ((TJROWS * J2S + 63) / 64) * 64 + 32;   // dwords between the two copies
+    static constexpr int J2COPY = ((TJROWS * J2S + 31) / 32) * 32 + 16;   // dwords between the two copies
     static constexpr int SD = (DW + 1) * DW;                 // ints of the derivative grid (+ one slack row)
     static constexpr int SJ2 = J2COPY + TJROWS * J2S;        // dwords of the two-copy search tile
     static constexpr int SI = (RROWS * RS + 3) / 4;          // dwords of the reference tile
@@ -65,11 +67,38 @@ constexpr int KLT_WAVES = KLT_THREADS / 64;
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 
+// Diagnostic builds (-DSVO_KLT_PHASES, tools/klt_phases.py): cycles of thread 0 per phase of the kernel,
+// summed over all wavefronts since the last read
+#ifdef SVO_KLT_PHASES
+// (1024 sets of counters, picked by the workgroup index: one set for all wavefronts made the atomics the
+// slowest part of the kernel)
+__device__ unsigned long long g_klt_phases[1024][16];
+#define KLT_SLOT_ ((blockIdx.x + 131u * blockIdx.y) & 1023u)
+#define KLT_PHASE(i)                                                                        \
+    do {                                                                                    \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();                     \
+        if (threadIdx.x == 0) atomicAdd(&g_klt_phases[KLT_SLOT_][i], t_now_ - t_phase_);    \
+        t_phase_ = t_now_;                                                                  \
+    } while (0)
+#define KLT_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_klt_phases[KLT_SLOT_][i], (unsigned long long)(v)); } while (0)
+#else
+#define KLT_PHASE(i) do { } while (0)
+#define KLT_COUNT(i, v) do { } while (0)
+#endif
+
+
 __device__ inline v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v); }
 __device__ inline int as_int(v2s v) { return __builtin_bit_cast(int, v); }
 __device__ inline int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
 // a.x*b.x + a.y*b.y + c, exact int32
 __device__ inline int dot2(v2s a, v2s b, int c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
+// the same with a wave-uniform c taken from a scalar register: the compiler only selects the accumulate-in-place
+// form (v_dot2c), which costs a v_mov of the constant into the destination first — 16 per window pass
+__device__ inline int dot2_uc(v2s a, v2s b, int c_uniform) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
 
 // LDS byte pairs. The window columns start at an arbitrary byte of the tile, and unaligned
 // ds_read_u16/b32 stall the LDS pipeline (SQ_LDS_UNALIGNED_STALL ~ its whole active time when
@@ -305,6 +334,10 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
     const int kp = blockIdx.x;
     if (kp >= n) return;
     const int tid = threadIdx.x;
+#ifdef SVO_KLT_PHASES
+    unsigned long long t_phase_ = __builtin_amdgcn_s_memtime();
+    KLT_COUNT(8, 1);
+#endif
     const int win = a.win;
     const int RW = win + 3, DW = win + 1, TJ = DW + 2 * KLT_MARGIN;
     const int lr = tid / CW, lc = tid - lr * CW;
@@ -369,6 +402,7 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
     float err = 0;
     const bool col_on = row_on && lc < win;
 
+    KLT_PHASE(0);                                  // prologue: arguments, keyframe record, projection
     for (int level = maxLevel; level >= 0; level--) {
         const ImgView I = kfp->lk[level];
         const ImgView J = a.cur[level];
@@ -513,6 +547,7 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             }
         }
         }   // template built here
+        KLT_PHASE(1);                              // template of the level requested (cache) or built
         if (lstate == KLT_OUTSIDE) {
             if (level == 0) { status = 0; err = 0; }
             continue;
@@ -536,13 +571,16 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             stage_tile_j2<GEO>(s_J2, J, tx0, ty0, TW >> 2, TJ);
             __syncthreads();
             have_tile = true;
+            KLT_COUNT(9, 1);
+            KLT_PHASE(2);                          // search tile staged (+ whatever loads were still in flight)
         };
         // J(x+d) of the thread's row pair k (5 fractional bits, like the template) for the window whose
         // rows were read into jr: the tile holds pixel << 7, so (sum + 2^8) >> 9 is the high half of
         // sum * 2^7 + 2^15, and the pair is the two high halves
+        const int round_half = __builtin_amdgcn_readfirstlane(1 << (W_BITS - 5 - 1 + 7));
         auto row_pair = [&](const int (&jr)[RPT + 1], const LkWeights& w, int k) -> v2s {
-            const int d0 = dot2(as_v2s(jr[2 * k]), w.top, dot2(as_v2s(jr[2 * k + 1]), w.bot, 1 << (W_BITS - 5 - 1 + 7)));
-            const int d1 = dot2(as_v2s(jr[2 * k + 1]), w.top, dot2(as_v2s(jr[2 * k + 2]), w.bot, 1 << (W_BITS - 5 - 1 + 7)));
+            const int d0 = dot2(as_v2s(jr[2 * k]), w.top, dot2_uc(as_v2s(jr[2 * k + 1]), w.bot, round_half));
+            const int d1 = dot2(as_v2s(jr[2 * k + 1]), w.top, dot2_uc(as_v2s(jr[2 * k + 2]), w.bot, round_half));
             return as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
         };
         // the bilinear pairs (p[x], p[x+1]) of the thread's column and rows for the window at tile offset (wx, wy)
@@ -557,6 +595,7 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
 #define SVO_KLT_MAXIT 30     /* (diagnostic builds count the instructions outside the iteration with 0) */
 #endif
         for (int j = 0; j < SVO_KLT_MAXIT; j++) {
+            KLT_COUNT(10, 1);
             const int inextx = cv_floor(nextx), inexty = cv_floor(nexty);
             if (inextx < -win || inextx >= J.w || inexty < -win || inexty >= J.h) {
                 if (level == 0) status = 0;
@@ -603,6 +642,7 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             }
             prevDx = dx; prevDy = dy;
         }
+        KLT_PHASE(3);                              // iterations
 
         if (status && level == 0) {
             const float npx = nx - halfWin, npy = ny - halfWin;
@@ -636,12 +676,30 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         }
     }
 
+    KLT_PHASE(4);                                  // error of the final position
     if (tid == 0) {
         G(a.cur_pts)[kp] = svo_kp2d{nx, ny};
         G(a.status)[kp] = (uint8_t)status;
         G(a.err)[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
     }
 }
+
+#ifdef SVO_KLT_PHASES
+}  // namespace svo
+// out[0..4]: cycles in prologue / template / tile staging / iterations / error pass, [8] wavefronts,
+// [9] tile stagings, [10] iterations; clears the counters
+extern "C" int svo_debug_klt_phases(unsigned long long* out16) {
+    static unsigned long long host[1024][16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(svo::g_klt_phases), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) {
+        out16[i] = 0;
+        for (int s = 0; s < 1024; s++) out16[i] += host[s][i];
+    }
+    memset(host, 0, sizeof(host));
+    return hipMemcpyToSymbol(HIP_SYMBOL(svo::g_klt_phases), host, sizeof(host)) == hipSuccess ? 0 : -1;
+}
+namespace svo {
+#endif
 
 // bytes of one keypoint's template of one level for window `win` (KfDev::tmpl)
 size_t klt_template_bytes(int win) {

@@ -285,10 +285,12 @@ __device__ __forceinline__ v2u pick5(int off, v2u m2, v2u m1, v2u z, v2u p1, v2u
     return off == -2 ? m2 : off == -1 ? m1 : off == 0 ? z : off == 1 ? p1 : p2;
 }
 
-constexpr int PS_RB = 64;       // level-0 rows per workgroup (one row of level 6)
-
+// RB: level-0 rows per workgroup. 64 = one row of level 6 (seven levels). Up to six levels 32 will do (one
+// row of level 5): twice the wavefronts — 8 per SIMD instead of 4 at C2 with 256 frames, every one with its
+// six rows in flight — for 10 more halo rows per 64, which the neighbour block reads at the same time (L2).
+template <int RB>
 __global__ __launch_bounds__(64) void pyr_stream_kernel(const PyrArgs* __restrict__ args, int batch) {
-    constexpr int RB = PS_RB;
+    static_assert(RB == 32 || RB == 64, "row block");
     const int lane = threadIdx.x;
     const int y0 = blockIdx.y * RB;
     if ((int)blockIdx.z >= batch) {
@@ -475,12 +477,12 @@ __global__ __launch_bounds__(64) void pyr_stream_kernel(const PyrArgs* __restric
                 s_l5[r][c] = (uint8_t)v;
                 d.gw()[(size_t)gy * d.stride + gx] = (uint8_t)v;
             }
-            if (n_levels > 6) {
+            if (RB >= 64 && n_levels > 6) {
                 __builtin_amdgcn_wave_barrier();
                 const ImgView d6 = a.level[6];
                 const int gx6 = (u0 >> 3) + lane, gy6 = y0 >> 6;
                 if (lane < PS_UNITS / 8 && gx6 < d6.w && gy6 < d6.h) {
-                    const int v = (s_l5[0][2 * lane] + s_l5[0][2 * lane + 1] + s_l5[1][2 * lane] + s_l5[1][2 * lane + 1]) >> 2;
+                    const int v = (s_l5[0][2 * lane] + s_l5[0][2 * lane + 1] + s_l5[RB / 64][2 * lane] + s_l5[RB / 64][2 * lane + 1]) >> 2;
                     d6.gw()[(size_t)gy6 * d6.stride + gx6] = (uint8_t)v;
                 }
             }
@@ -488,30 +490,32 @@ __global__ __launch_bounds__(64) void pyr_stream_kernel(const PyrArgs* __restric
     }
 }
 
-// the conditions of the streaming kernel: 8-pixel units, even height, aligned rows everywhere it
+// 0, or the row block of the streaming kernel when its conditions hold: 8-pixel units, even height, aligned rows everywhere it
 // uses wide accesses (every buffer the tracker allocates; a caller's image when its pointer and
 // stride are multiples of 8)
-bool pyr_stream_ok(const PyrArgs& a) {
+int pyr_stream_rows(const PyrArgs& a) {
     auto al = [](const ImgView& v, uintptr_t m) { return ((reinterpret_cast<uintptr_t>(v.data) | (uintptr_t)v.stride) & m) == 0; };
     const bool ingest = a.src_left.data != nullptr;
     const ImgView& src = ingest ? a.src_left : a.level[0];
-    if (src.w % 8 || src.h % 2 || src.w < 16 || src.h < 16 || !al(src, 7)) return false;
-    if (a.n_levels > 7 || a.n_lk > 3) return false;
-    if (ingest && a.level[0].data != a.src_left.data && !al(a.level[0], 7)) return false;
-    if (a.src_right.data && (!al(a.src_right, 7) || !al(a.dst_right, 7))) return false;
-    if (a.n_levels > 1 && !al(a.level[1], 3)) return false;
-    if (a.n_levels > 2 && !al(a.level[2], 1)) return false;
-    if (a.n_lk > 1 && !al(a.lk[1], 3)) return false;
-    if (a.n_lk > 2 && !al(a.lk[2], 1)) return false;
-    return true;
+    if (src.w % 8 || src.h % 2 || src.w < 16 || src.h < 16 || !al(src, 7)) return 0;
+    if (a.n_levels > 7 || a.n_lk > 3) return 0;
+    if (ingest && a.level[0].data != a.src_left.data && !al(a.level[0], 7)) return 0;
+    if (a.src_right.data && (!al(a.src_right, 7) || !al(a.dst_right, 7))) return 0;
+    if (a.n_levels > 1 && !al(a.level[1], 3)) return 0;
+    if (a.n_levels > 2 && !al(a.level[2], 1)) return 0;
+    if (a.n_lk > 1 && !al(a.lk[1], 3)) return 0;
+    if (a.n_lk > 2 && !al(a.lk[2], 1)) return 0;
+    return a.n_levels > 6 ? 64 : 32;
 }
 
-void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, bool stream_ok, hipStream_t stream) {
-    const char* env = getenv("SVO_PYR_KERNEL");          // "tile": always the tile kernel (tests, A/B runs)
-    if (stream_ok && !(env && env[0] == 't')) {
+void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, int stream_rows, hipStream_t stream) {
+    const char* env = getenv("SVO_PYR_KERNEL");          // "tile": always the tile kernel; "64": 64-row blocks (tests, A/B runs)
+    if (stream_rows > 0 && !(env && env[0] == 't')) {
         const int units = w / 8;
-        dim3 grid((units + PS_UNITS - 1) / PS_UNITS, (h + PS_RB - 1) / PS_RB, right_blocks ? 2 * batch : batch);
-        hipLaunchKernelGGL(pyr_stream_kernel, grid, dim3(64), 0, stream, d_args, batch);
+        if (env && env[0] == '6') stream_rows = 64;
+        dim3 grid((units + PS_UNITS - 1) / PS_UNITS, (h + stream_rows - 1) / stream_rows, right_blocks ? 2 * batch : batch);
+        if (stream_rows == 32) hipLaunchKernelGGL(pyr_stream_kernel<32>, grid, dim3(64), 0, stream, d_args, batch);
+        else hipLaunchKernelGGL(pyr_stream_kernel<64>, grid, dim3(64), 0, stream, d_args, batch);
         return;
     }
     dim3 grid((w + PF_T - 1) / PF_T, (h + PF_T - 1) / PF_T, right_blocks ? 2 * batch : batch);

@@ -198,7 +198,7 @@ extern "C" int svo_build_pyramid(svo_handle* h, int n_levels, svo_image* levels)
     PyrArgs* d;
     int rc = stage(h, pa, &d);
     if (rc) return rc;
-    if (n_levels > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, pyr_stream_ok(pa), h->stream);
+    if (n_levels > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, pyr_stream_rows(pa), h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -224,7 +224,7 @@ extern "C" int svo_build_lk_pyramid(svo_handle* h, int max_levels, int win, svo_
     PyrArgs* d;
     int rc = stage(h, pa, &d);
     if (rc) return rc;
-    if (n > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, pyr_stream_ok(pa), h->stream);
+    if (n > 1) launch_pyr_fused(d, 1, levels[0].width, levels[0].height, false, pyr_stream_rows(pa), h->stream);
     HIP_TRY(hipGetLastError());
     if (n_out) *n_out = n;
     return SVO_OK;

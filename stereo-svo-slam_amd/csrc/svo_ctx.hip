@@ -854,7 +854,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             }
         }
     }
-    bool pyr_stream = true;            // every frame of the step fits the row-streaming pyramid kernel
+    int pyr_stream = -1;               // row block of the row-streaming pyramid kernel, 0: some frame of the step does not fit it
     for (int j = 0; j < M; j++) {
         const int s = act[j];
         Seq& q = c->seqs[s];
@@ -886,7 +886,10 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         for (int l = 0; l < hs->n_levels; l++) hs->level[l] = is->left[l];
         hs->n_lk = c->n_lk;
         for (int l = 0; l < c->n_lk; l++) hs->lk[l] = is->lk[l];
-        pyr_stream = pyr_stream && pyr_stream_ok(*hs);
+        {
+            const int rows = pyr_stream_rows(*hs);
+            pyr_stream = (pyr_stream == 0 || rows == 0) ? 0 : std::max(pyr_stream, rows);
+        }
     }
 
     if (!first) {
@@ -952,7 +955,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
     hlap(0);   // argument blocks
     HIP_TRY(hipMemcpyAsync(c->d_args, c->h_args, first ? c->args_bytes : c->frame_args_bytes,
                            hipMemcpyHostToDevice, c->stream));
-    launch_pyr_fused(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, mem != SVO_MEM_DEVICE_BORROW, pyr_stream, c->stream);
+    launch_pyr_fused(dargs_at<PyrArgs>(c, c->off_hs), M, c->width, c->height, mem != SVO_MEM_DEVICE_BORROW, std::max(pyr_stream, 0), c->stream);
     HIP_TRY(hipGetLastError());   // (every launch is checked on its own: a later success must not mask a failure)
     std::vector<int> need(B, 0);
     if (first) {

@@ -44,9 +44,10 @@ struct PyrArgs {
 };
 // both pyramids of `batch` left images of w x h in one launch; right_blocks: extra workgroups copy
 // src_right -> dst_right (ingest of device-resident frames)
-// stream_ok: pyr_stream_ok() holds for every argument block of the launch (the row-streaming kernel; else the tile kernel)
-void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, bool stream_ok, hipStream_t stream);
-bool pyr_stream_ok(const PyrArgs& host_args);
+// stream_rows: 0 if pyr_stream_rows() is 0 for any argument block of the launch (then the tile kernel), else the
+// largest of them (the row-streaming kernel with that row block)
+void launch_pyr_fused(const PyrArgs* d_args, int batch, int w, int h, bool right_blocks, int stream_rows, hipStream_t stream);
+int pyr_stream_rows(const PyrArgs& host_args);
 
 // ------------------------------------------------- sparse image alignment
 struct SiaArgs {

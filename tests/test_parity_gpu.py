@@ -32,12 +32,13 @@ def cam_of(cfg):
 
 # ------------------------------------------------------------------ P1 / P2
 # Two kernels build the pyramids: the row-streaming one (width a multiple of 8, even height, aligned
-# rows: every configuration of the reference) and the tile kernel (anything else, or SVO_PYR_KERNEL=tile).
+# rows: every configuration of the reference; row blocks of 32 up to six levels, of 64 with seven or with
+# SVO_PYR_KERNEL=64) and the tile kernel (anything else, or SVO_PYR_KERNEL=tile).
 STREAM_SHAPES = [((480, 752), 6), ((240, 320), 4), ((1080, 1920), 7), ((64, 64), 4), ((48, 456), 4),
                  ((130, 904), 5), ((16, 16), 3), ((66, 3584), 6)]
 
 
-@pytest.mark.parametrize("kernel", ["stream", "tile"])
+@pytest.mark.parametrize("kernel", ["stream", "64", "tile"])
 @pytest.mark.parametrize("shape,levels", STREAM_SHAPES + [((131, 203), 5)])
 def test_halfsample_pyramid_bit_exact(H, shape, levels, kernel, monkeypatch):
     monkeypatch.setenv("SVO_PYR_KERNEL", kernel)
@@ -57,7 +58,7 @@ def test_halfsample_pyramid_real_image(H):
         assert np.array_equal(got[l].cpu().numpy(), ref[l])
 
 
-@pytest.mark.parametrize("kernel", ["stream", "tile"])
+@pytest.mark.parametrize("kernel", ["stream", "64", "tile"])
 @pytest.mark.parametrize("shape,win", [((480, 752), 31), ((240, 320), 21), ((97, 131), 21),
                                        ((1080, 1920), 31), ((64, 72), 9), ((130, 904), 31), ((66, 456), 9),
                                        ((34, 3584), 5), ((482, 752), 31), ((476, 752), 31)])
