@@ -111,7 +111,7 @@ void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t s
 
 // --------------------------------------------------------------- detection
 constexpr int DET_MAX_CW = 96, DET_MAX_CH = 64;
-constexpr int DET_TW = DET_MAX_CW + 8, DET_TH = DET_MAX_CH + 8;   // cell + 4 px halo
+constexpr int DET_TW = DET_MAX_CW + 12, DET_TH = DET_MAX_CH + 8;  // cell + 4 px halo (+ up to 3 columns in front: rows staged from a dword boundary)
 constexpr int DET_RW = DET_MAX_CW + 2, DET_RH = DET_MAX_CH + 2;   // raw scores: cell + 1 px
 
 __constant__ int c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -122,45 +122,52 @@ __constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 
 // cornerScore<16> on the corners only (kf_detect_kernel gathers them first: the score is 2/3 of the work
 // and most pixels are no corners, but nearly every wavefront holds one)
 __device__ inline bool fast_is_corner(const uint8_t* p, int stride, int threshold) {
+    // ring pixel q is darker than the centre v by more than the threshold iff q - (v - t) < 0, brighter iff
+    // (v + t) - q < 0: the sign bits are shifted into two 16-bit masks (v_alignbit: one instruction per bit),
+    // and "nine contiguous on the circle" is a run of nine in the mask repeated twice
     const int v = p[0];
-    int d[16];
+    const int lo = v - threshold, hi = v + threshold;
+    unsigned md = 0, mb = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)p[c_ring_dy[k] * stride + c_ring_dx[k]];
-    bool corner = false;
-    int cd = 0, cb = 0;
-#pragma unroll
-    for (int k = 0; k < 25; k++) {
-        cd = (d[k & 15] > threshold) ? cd + 1 : 0;
-        cb = (d[k & 15] < -threshold) ? cb + 1 : 0;
-        corner = corner || cd > 8 || cb > 8;
+    for (int k = 0; k < 16; k++) {
+        const int q = p[c_ring_dy[k] * stride + c_ring_dx[k]];
+        md = __builtin_amdgcn_alignbit(md, (unsigned)(q - lo), 31);
+        mb = __builtin_amdgcn_alignbit(mb, (unsigned)(hi - q), 31);
     }
-    return corner;
+    auto run9 = [](unsigned m) {
+        const unsigned w = m | (m << 16);
+        unsigned r = w & (w >> 1);          // runs of 2, 4, 8 starting at a bit
+        r &= r >> 2;
+        r &= r >> 4;
+        return (r & (w >> 8)) != 0;         // ... and the ninth
+    };
+    return run9(md) || run9(mb);
 }
 __device__ inline int fast_corner_score(const uint8_t* p, int stride, int threshold) {
+    // cornerScore<16>: OpenCV leaves an arc as soon as its first three (five) differences cannot raise the
+    // score; without those exits the result is the same (the running min / max of an arc only falls / rises,
+    // so it ends at or below a0 / at or above b0), the code has no divergent branches, and min / max pair up
+    // as v_min3 / v_max3. Pair minima are shared by the eight arcs: m(k) = min d[k+1 .. k+8].
     int d[25];
     const int v = p[0];
 #pragma unroll
     for (int k = 0; k < 25; k++) d[k] = v - (int)p[c_ring_dy[k & 15] * stride + c_ring_dx[k & 15]];
+    int pmin[12], pmax[12];                       // of d[2j+1], d[2j+2]
+#pragma unroll
+    for (int j = 0; j < 12; j++) { pmin[j] = min(d[2 * j + 1], d[2 * j + 2]); pmax[j] = max(d[2 * j + 1], d[2 * j + 2]); }
     int a0 = threshold;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
-        int a = min(d[k + 1], d[k + 2]);
-        a = min(a, d[k + 3]);
-        if (a <= a0) continue;
-        a = min(a, d[k + 4]); a = min(a, d[k + 5]); a = min(a, d[k + 6]);
-        a = min(a, d[k + 7]); a = min(a, d[k + 8]);
-        a0 = max(a0, min(a, d[k]));
-        a0 = max(a0, min(a, d[k + 9]));
+        const int j = k >> 1;
+        const int a = min(min(min(pmin[j], pmin[j + 1]), pmin[j + 2]), pmin[j + 3]);
+        a0 = max(max(a0, min(a, d[k])), min(a, d[k + 9]));
     }
     int b0 = -a0;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
-        int b = max(d[k + 1], d[k + 2]);
-        b = max(b, d[k + 3]); b = max(b, d[k + 4]); b = max(b, d[k + 5]);
-        if (b >= b0) continue;
-        b = max(b, d[k + 6]); b = max(b, d[k + 7]); b = max(b, d[k + 8]);
-        b0 = min(b0, max(b, d[k]));
-        b0 = min(b0, max(b, d[k + 9]));
+        const int j = k >> 1;
+        const int b = max(max(max(pmax[j], pmax[j + 1]), pmax[j + 2]), pmax[j + 3]);
+        b0 = min(min(b0, max(b, d[k])), max(b, d[k + 9]));
     }
     return -b0 - 1;
 }
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     const int left = cxi * gw, top = cyi * gh;
     const int tid = threadIdx.x;
 
-    __shared__ uint8_t s_t[DET_TH * DET_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[DET_TH * DET_TW];
     __shared__ uint8_t s_raw[DET_RH * DET_RW];
     __shared__ unsigned s_key[4];
     __shared__ uint16_t s_list[DET_LIST];
@@ -201,11 +208,28 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
 
     const int tw = gw + 8, th = gh + 8;
     const SmallDiv div_tw(tw), div_rw(gw + 2), div_gw(gw), div_gh(gh);
-    for (int i = tid; i < tw * th; i += 256) {
-        int r, c;
-        div_tw.divmod(i, r, c);
-        const int gy = reflect101(top - 4 + r, im.h), gx = reflect101(left - 4 + c, im.w);
-        s_t[r * DET_TW + c] = im.g()[(size_t)gy * im.stride + gx];
+    // the cell + 4 px: inside the image whole dwords from the dword boundary left of its first column (column c of
+    // the tile is byte ox + c of an LDS row), at the image border byte by byte with BORDER_REFLECT_101
+    const int x0 = (left - 4) & ~3, ox = (left - 4) - x0;
+    const bool inside = left - 4 >= 0 && top - 4 >= 0 && left + gw + 4 <= im.w && top + gh + 4 <= im.h && x0 + ((ox + tw + 3) & ~3) <= im.stride &&
+                        (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
+    const uint8_t* const s_tb = s_t + (inside ? ox : 0);
+    if (inside) {
+        const int nq = (ox + tw + 3) >> 2;
+        const SmallDiv div_nq(nq);
+        SVO_GP(const uint8_t) g0 = im.g() + (size_t)(top - 4) * im.stride + x0;
+        for (int i = tid; i < nq * th; i += 256) {
+            int r, c;
+            div_nq.divmod(i, r, c);
+            *reinterpret_cast<uint32_t*>(&s_t[r * DET_TW + 4 * c]) = *reinterpret_cast<SVO_GP(const uint32_t)>(g0 + r * im.stride + 4 * c);
+        }
+    } else {
+        for (int i = tid; i < tw * th; i += 256) {
+            int r, c;
+            div_tw.divmod(i, r, c);
+            const int gy = reflect101(top - 4 + r, im.h), gx = reflect101(left - 4 + c, im.w);
+            s_t[r * DET_TW + c] = im.g()[(size_t)gy * im.stride + gx];
+        }
     }
     __syncthreads();
     // raw FAST scores on the cell + 1 px (0 outside the detector's 3 px border): corner test everywhere,
@@ -219,10 +243,10 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
         const int gy = top - 1 + r, gx = left - 1 + c;
         int sc = 0;
         if (gx >= 3 && gx < im.w - 3 && gy >= 3 && gy < im.h - 3 &&
-            fast_is_corner(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6)) {
+            fast_is_corner(&s_tb[(r + 3) * DET_TW + c + 3], DET_TW, 6)) {
             const int slot = atomicAdd(&s_nlist, 1);
             if (slot < DET_LIST) s_list[slot] = (uint16_t)i;
-            else sc = fast_corner_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+            else sc = fast_corner_score(&s_tb[(r + 3) * DET_TW + c + 3], DET_TW, 6);
         }
         s_raw[r * DET_RW + c] = (uint8_t)sc;
     }
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
             const int i = s_list[q];
             int r, c;
             div_rw.divmod(i, r, c);
-            s_raw[r * DET_RW + c] = (uint8_t)fast_corner_score(&s_t[(r + 3) * DET_TW + c + 3], DET_TW, 6);
+            s_raw[r * DET_RW + c] = (uint8_t)fast_corner_score(&s_tb[(r + 3) * DET_TW + c + 3], DET_TW, 6);
         }
     }
     __syncthreads();
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
         for (int i = tid; i < gw * gh; i += 256) {
             int c, r;
             div_gh.divmod(i, c, r);                  // order index = x*gh + y
-            const uint8_t* p1 = &s_t[(r + 4) * DET_TW + c + 4];
+            const uint8_t* p1 = &s_tb[(r + 4) * DET_TW + c + 4];
             const uint8_t* p0 = p1 - DET_TW;
             const uint8_t* p2 = p1 + DET_TW;
             int v = (p0[1] - p0[-1]) + 2 * (p1[1] - p1[-1]) + (p2[1] - p2[-1]);
