@@ -513,6 +513,7 @@ def main():
         "single_sequence_speedup_vs_one_core": (single["frames_per_s"] / cpu["value"]) if cpu and cpu["value"] and single else None,
         "parity_max_abs_pose_diff": cpu and cpu["parity"] and cpu["parity"]["max_abs_pose_diff"],
         "parity_sequences_compared": cpu and cpu["parity"] and cpu["parity"]["sequences_compared"],
+        "parity_groups_covered": cpu and cpu["parity"] and cpu["parity"]["groups_covered"],
         "valu_issue_frac_of_step": valu and valu["frac"],
         "issue_active_frac_of_step": issue and issue["per_simd_cycle"],
         "c3_fps": c3 and c3["frames_per_s"], "c3_pyramids_hbm_frac": c3 and c3["pyramids_hbm_frac"],

@@ -54,14 +54,12 @@ __device__ inline uint4 load_u8x16(const ImgView& im, int y, int x, int valid, u
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-constexpr int SSD_MAX_WIN = 35;                 // template edge
-constexpr int SSD_MAX_MH = 17, SSD_MAX_MW = 65; // match map: (2*search_y+1) x (search_x+1)
+constexpr int SSD_WIN_ALL = 35, SSD_MH_ALL = 17; // template edge and match-map rows (2*search_y+1) the entry points accept
+constexpr int SSD_MAX_MW = 65;                  // match-map columns (search_x+1)
 constexpr int SSD_T_STRIDE = 96;                // bytes per padded template row: 16 zeros | row | zeros
 constexpr int SSD_R_STRIDE = 144;               // bytes per search-region row (36 dwords: conflict-free b128 rows)
-constexpr int SSD_R_ROWS = SSD_MAX_WIN + SSD_MAX_MH;   // 52
 constexpr int SSD_W_STRIDE = 105;               // ints per row of the column sums (= 1 mod 8: the 8 rows x 8 segments of 8 columns
                                                 // that a wave reads in the row pass hit 64 different banks; 100 was a 4-way conflict)
-constexpr int SSD_MAX_MATCH = SSD_MAX_MW * SSD_MAX_MH;
 #ifndef SVO_SSD_THREADS
 #define SVO_SSD_THREADS 256
 #endif
@@ -85,7 +83,12 @@ typedef int ssd_v4i __attribute__((ext_vector_type(4)));
 //    16*(l>>4) .. +15 of its row / column for both operands.
 //  * sum_w R^2: sliding window sums, columns first (one thread per region column), then rows.
 //  * argmin (first minimum in row-major order) and the tie-averaged column of :313-323 as before.
+// SSD_MAX_WIN / SSD_MAX_MH: what the LDS is sized for. The window kernels of a step share each CU's 160 KB with
+// the alignment kernel's 38 KB per wavefront, and what fits is what runs: the shape for windows up to 31 and
+// search_y up to 6 (every configuration of the reference) takes 14.9 KB instead of 18.2.
+template <int SSD_MAX_WIN, int SSD_MAX_MH>
 __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArgs* __restrict__ args) {
+    constexpr int SSD_R_ROWS = SSD_MAX_WIN + SSD_MAX_MH, SSD_MAX_MATCH = SSD_MAX_MW * SSD_MAX_MH;
     const SsdArgs& a = args[blockIdx.y];
     if (a.enable && !*G(a.enable)) return;
     const int n = *G(a.n_ptr);
@@ -288,9 +291,12 @@ __global__ __launch_bounds__(SSD_THREADS) void ssd_disparity_kernel(const SsdArg
     }
 }
 
-void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream) {
+void launch_ssd(const SsdArgs* d_args, int batch, int max_n, int win, int search_y, hipStream_t stream) {
     if (max_n <= 0) return;
-    hipLaunchKernelGGL(ssd_disparity_kernel, dim3(max_n, batch), dim3(SSD_THREADS), 0, stream, d_args);
+    if (win <= 31 && 2 * search_y + 1 <= 13)
+        hipLaunchKernelGGL((ssd_disparity_kernel<31, 13>), dim3(max_n, batch), dim3(SSD_THREADS), 0, stream, d_args);
+    else
+        hipLaunchKernelGGL((ssd_disparity_kernel<SSD_WIN_ALL, SSD_MH_ALL>), dim3(max_n, batch), dim3(SSD_THREADS), 0, stream, d_args);
 }
 
 // -------------------------------------------------------------------------

@@ -110,9 +110,7 @@ void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t s
 }
 
 // --------------------------------------------------------------- detection
-constexpr int DET_MAX_CW = 96, DET_MAX_CH = 64;
-constexpr int DET_TW = DET_MAX_CW + 12, DET_TH = DET_MAX_CH + 8;  // cell + 4 px halo (+ up to 3 columns in front: rows staged from a dword boundary)
-constexpr int DET_RW = DET_MAX_CW + 2, DET_RH = DET_MAX_CH + 2;   // raw scores: cell + 1 px
+constexpr int DET_MAX_CW = 96, DET_MAX_CH = 64;      // largest cell (grid_width x grid_height) the tracker accepts
 
 __constant__ int c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 __constant__ int c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
@@ -183,16 +181,21 @@ struct SmallDiv {
     __device__ void divmod(int i, int& q, int& r) const { q = quot(i); r = i - q * d; }
 };
 
-constexpr int DET_LIST = 2048;    // corners of a cell kept for the score pass (more: scored where they are found)
+// Shapes of kf_detect_kernel: cells up to CW x CH, DET_LIST corners kept for the score pass (more: scored where they are
+// found). The LDS of the window kernels decides how many of them share a CU with the alignment kernel: cells up to
+// 56 x 48 (C2, C3) take 9 KB instead of the 18.4 KB of the largest shape.
 
+template <int CW, int CH, int DET_LIST>
 __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __restrict__ args) {
+    constexpr int DET_TW = ((CW + 8 + 3 + 3) & ~3), DET_TH = CH + 8;   // cell + 4 px halo (+ up to 3 columns in front: rows staged from a dword boundary)
+    constexpr int DET_RW = CW + 2, DET_RH = CH + 2;                  // raw scores: cell + 1 px
     const DetectArgs& a = args[blockIdx.z];
     if (a.enable && !*G(a.enable)) return;
     const int level = blockIdx.y;
     if (level >= a.n_levels) return;
     const ImgView im = a.level[level];
     const int gw = a.grid_w >> level, gh = a.grid_h >> level;
-    if (gw <= 0 || gh <= 0 || gw > DET_MAX_CW || gh > DET_MAX_CH) return;
+    if (gw <= 0 || gh <= 0 || gw > CW || gh > CH) return;
     const int ncx = im.w / gw, ncy = max(im.h / gh, 1);
     const int cell = blockIdx.x;
     if (cell >= ncx * ncy) return;
@@ -321,8 +324,11 @@ __global__ __launch_bounds__(256) void kf_detect_kernel(const DetectArgs* __rest
     }
 }
 
-void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, hipStream_t stream) {
-    hipLaunchKernelGGL(kf_detect_kernel, dim3(max_cells, n_levels, batch), dim3(256), 0, stream, d_args);
+void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, int grid_w, int grid_h, hipStream_t stream) {
+    if (grid_w <= 56 && grid_h <= 48)
+        hipLaunchKernelGGL((kf_detect_kernel<56, 48, 1024>), dim3(max_cells, n_levels, batch), dim3(256), 0, stream, d_args);
+    else
+        hipLaunchKernelGGL((kf_detect_kernel<DET_MAX_CW, DET_MAX_CH, 2048>), dim3(max_cells, n_levels, batch), dim3(256), 0, stream, d_args);
 }
 
 // --------------------------------------------------------- select + merge

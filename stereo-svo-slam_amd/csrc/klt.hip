@@ -81,7 +81,9 @@ __device__ unsigned long long g_klt_phases[1024][16];
         t_phase_ = t_now_;                                                                  \
     } while (0)
 #define KLT_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_klt_phases[KLT_SLOT_][i], (unsigned long long)(v)); } while (0)
+#define KLT_PHASE_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KLT_PHASE(i); } while (0)
 #else
+#define KLT_PHASE_WAIT(i) do { } while (0)
 #define KLT_PHASE(i) do { } while (0)
 #define KLT_COUNT(i, v) do { } while (0)
 #endif
@@ -430,14 +432,18 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             rec = (SVO_GP(uint4))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level) * KltTmpl<NPAIR>::BYTES);
             vflag = G(kfp->tmpl_valid) + kpi * SVO_LK_LEVELS + level;
         }
+        KLT_PHASE(5);                              // (diagnostic split of phase 1: addresses of the level)
         const bool hit = vflag && *vflag != 0;
+        KLT_PHASE_WAIT(6);                         // ... the "stored" flag has arrived
         if (hit) {
             SVO_GP(const KltTmplHeader) hd = (SVO_GP(const KltTmplHeader))(rec + KltTmpl<NPAIR>::TQ * 64);
             lstate = hd->state; A11 = hd->A11; A12 = hd->A12; A22 = hd->A22; cI1 = hd->cI1; cI2 = hd->cI2;
+            KLT_PHASE_WAIT(7);                     // ... the header
             if (lstate == KLT_TRACK) {
                 uint4 v[KltTmpl<NPAIR>::TQ];
 #pragma unroll
                 for (int q = 0; q < KltTmpl<NPAIR>::TQ; q++) v[q] = rec[q * 64 + tid];
+                KLT_PHASE_WAIT(11);                // ... the template (the product code does not wait here)
                 const uint32_t* f = reinterpret_cast<const uint32_t*>(v);
 #pragma unroll
                 for (int k = 0; k < NPAIR; k++) { tIw[k] = (int)f[k]; tIx[k] = (int)f[NPAIR + k]; tIy[k] = (int)f[2 * NPAIR + k]; }
@@ -558,6 +564,18 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         }
         float D = A11 * A22 - A12 * A12;
         D = 1.f / D;
+#ifdef SVO_KLT_PREFETCH
+        // (experiment) touch the next level's template and search tile now: one byte per 128 bytes of the record, one per
+        // row of the tile around twice the current position; they arrive in L2 while this level iterates
+        int pf0 = 0, pf1 = 0;
+        if (level > 0 && tmpl_base && kpi < tmpl_cap) {
+            SVO_GP(const uint8_t) nrec = (SVO_GP(const uint8_t))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level - 1) * KltTmpl<NPAIR>::BYTES);
+            if (tid * 128 < KltTmpl<NPAIR>::BYTES) pf0 = nrec[tid * 128];
+            const ImgView Jn = a.cur[level - 1];
+            const int qx = cv_floor(nx * 2.f - halfWin) - KLT_MARGIN, qy = cv_floor(ny * 2.f - halfWin) - KLT_MARGIN + tid;
+            if (tid < TJ && qx >= 0 && qx + TJ + 8 <= Jn.w && qy >= 0 && qy < Jn.h) pf1 = Jn.g()[M24(qy, Jn.stride) + qx + 24];
+        }
+#endif
         nextx -= halfWin; nexty -= halfWin;
         float prevDx = 0, prevDy = 0;
         int tx0 = 0, ty0 = 0;
@@ -568,7 +586,9 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         auto load_tile = [&](int cx, int cy) {
             tx0 = (cx - KLT_MARGIN) & ~3; ty0 = cy - KLT_MARGIN;
             __syncthreads();
+            KLT_PHASE_WAIT(12);                    // (diagnostic: everything requested before the tile has arrived)
             stage_tile_j2<GEO>(s_J2, J, tx0, ty0, TW >> 2, TJ);
+            KLT_PHASE_WAIT(13);                    // (... the tile's loads and its LDS stores)
             __syncthreads();
             have_tile = true;
             KLT_COUNT(9, 1);
@@ -642,6 +662,9 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             }
             prevDx = dx; prevDy = dy;
         }
+#ifdef SVO_KLT_PREFETCH
+        asm volatile("" ::"v"(pf0), "v"(pf1));
+#endif
         KLT_PHASE(3);                              // iterations
 
         if (status && level == 0) {

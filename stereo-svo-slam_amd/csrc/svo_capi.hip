@@ -351,7 +351,7 @@ extern "C" int svo_ssd_disparity(svo_handle* h, const svo_image* left, const svo
     SsdArgs* d;
     rc = stage(h, sa, &d);
     if (rc) return rc;
-    launch_ssd(d, 1, n, h->stream);
+    launch_ssd(d, 1, n, win, search_y, h->stream);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }

@@ -783,12 +783,12 @@ static int enqueue_keyframes(svo_group* c, const std::vector<int>& need, bool fi
     launch_compact(dargs_at<CompactArgs>(c, c->off_compact), m, c->cap, c->stream);
     HIP_TRY(hipGetLastError());
     if (c->det_levels > 0) {
-        launch_detect(dargs_at<DetectArgs>(c, c->off_det), m, c->max_cells, c->det_levels, c->stream);
+        launch_detect(dargs_at<DetectArgs>(c, c->off_det), m, c->max_cells, c->det_levels, c->cam.grid_width, c->cam.grid_height, c->stream);
         HIP_TRY(hipGetLastError());
     }
     launch_select_merge(dargs_at<MergeArgs>(c, c->off_merge), m, c->max_cells, c->stream);
     HIP_TRY(hipGetLastError());
-    launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), m, c->cap, c->stream);
+    launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), m, c->cap, c->cam.window_size_depth_calculator, c->cam.search_y, c->stream);
     HIP_TRY(hipGetLastError());
     launch_kf_init(dargs_at<KfInitArgs>(c, c->off_init), m, c->stream);
     HIP_TRY(hipGetLastError());
@@ -990,7 +990,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
         }
         HIP_TRY(hipGetLastError());
         SVO_MARK(5);
-        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->stream);
+        launch_ssd(dargs_at<SsdArgs>(c, c->off_ssd), M, grid_n, c->cam.window_size_depth_calculator, c->cam.search_y, c->stream);
         HIP_TRY(hipGetLastError());
         SVO_MARK(6);
         launch_filter(dargs_at<FilterArgs>(c, c->off_filt), M, grid_n, c->stream);

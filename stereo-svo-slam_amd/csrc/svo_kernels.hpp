@@ -155,7 +155,8 @@ struct SsdArgs {
     const int* first_ptr;         // optional device value added to `first`
     const int* enable;            // optional device predicate
 };
-void launch_ssd(const SsdArgs* d_args, int batch, int max_n, hipStream_t stream);
+// win / search_y: the largest SsdArgs::win / search_y of the launch (choose the LDS size of the kernel)
+void launch_ssd(const SsdArgs* d_args, int batch, int max_n, int win, int search_y, hipStream_t stream);
 
 struct FilterArgs {
     svo_camera_settings cam;

@@ -49,7 +49,8 @@ struct DetectArgs {
     int max_cells;
     const int* enable;
 };
-void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, hipStream_t stream);
+// grid_w x grid_h: the level-0 cell of the launch's sequences (chooses the kernel shape)
+void launch_detect(const DetectArgs* d_args, int batch, int max_cells, int n_levels, int grid_w, int grid_h, hipStream_t stream);
 
 struct MergeArgs {
     svo_camera_settings cam;

@@ -265,7 +265,31 @@ class Replay:
         if time_trace:
             self.slam.enable_timing(True)
 
-    def feed(self, left, right, time_stamp):
+    IMU_RATE = 104.0                              # samples per second the Econ camera's IMU thread delivers
+
+    def update_pose_from_imu(self, gyro_deg_s, dt):
+        """SlamApp::update_pose_from_imu (slam_app.cpp:111-135): between two frames the pose filter is fed
+        the gyro rates of at most IMU_RATE * dt samples ([n, 3] degrees per second, x y z) as the speed
+        measurement with the app's variances, one StereoSlam::update_pose call of 1 / IMU_RATE each;
+        nothing happens before the first frame. Returns the filtered pose (the app discards it: the calls
+        act through the filter's state)."""
+        if self.slam._ctx is None:                # (the ctx is created by the first frame)
+            return None
+        gyro = np.asarray(gyro_deg_s, np.float32).reshape(-1, 3)
+        pose_variance = np.full(6, 1000.0, np.float32)
+        speed_variance = np.array([100.0, 100.0, 100.0, 0.1, 0.1, 0.1], np.float32)
+        pose = np.asarray(self.slam.pose(), np.float32)
+        n = min(len(gyro), int(np.float32(self.IMU_RATE) * np.float32(dt)))    # std::min<size_t>(size, f * dt): truncated
+        for g in gyro[:n]:
+            speed = np.zeros(6, np.float32)
+            speed[3:] = (g.astype(np.float64) / 180.0 * math.pi).astype(np.float32)
+            pose = self.slam.update_pose(pose, speed, pose_variance, speed_variance, 1.0 / self.IMU_RATE)   # double 1.0 / f
+        return pose
+
+    def feed(self, left, right, time_stamp, gyro_deg_s=None, images_read=1):
+        """process_image (slam_app.cpp:160-196); with IMU samples: update_pose_from_imu(images_read / 30) first"""
+        if gyro_deg_s is not None:
+            self.update_pose_from_imu(gyro_deg_s, images_read / 30.0)
         t0 = time.perf_counter()
         self.slam.new_image(left, right, time_stamp)
         self._t += time.perf_counter() - t0

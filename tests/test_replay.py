@@ -237,3 +237,46 @@ def test_replay_default_trace_is_the_oracles_and_time_trace_runs(capsys):
             assert sum(a.stage_ms) > 0
     out = capsys.readouterr().out
     assert out.count("Stereo SLAM took:") == 5 and "estimator took:" in out
+
+
+@pytest.mark.gpu
+def test_replay_imu_loop_equals_the_oracle():
+    """update_pose_from_imu (slam_app.cpp:111-135): the gyro samples that arrived since the last frame go
+    through the pose filter before the next new_image — at most 104 * images_read / 30 of them, none
+    before the first frame. The same calls on the oracle give the same poses, bit for bit."""
+    import math
+    import oracle_py as O
+    import util
+    cfg, L, R, poses, ts = synth.make_sequence("tiny", 5, 7, device="cpu")
+    ref = O.Slam(util.oracle_camera(cfg))
+    rp = replay.Replay(cfg)
+    rng = np.random.RandomState(3)
+    pv = np.full(6, 1000.0, np.float32)
+    sv = np.array([100.0, 100.0, 100.0, 0.1, 0.1, 0.1], np.float32)
+    for k in range(5):
+        gyro = rng.normal(0, 2.0, (5, 3)).astype(np.float32)          # degrees per second; 5 arrive, 3 are used
+        images_read = 1
+        got = rp.update_pose_from_imu(gyro, images_read / 30.0) if k != 2 else None
+        if k == 0:
+            assert got is None                                        # no frame yet
+        elif k != 2:
+            n_used = min(len(gyro), int(np.float32(104.0) * np.float32(images_read / 30.0)))
+            assert n_used == 3
+            pose = ref.pose().astype(np.float32)
+            for g in gyro[:n_used]:
+                speed = np.zeros(6, np.float32)
+                speed[3:] = (g.astype(np.float64) / 180.0 * math.pi).astype(np.float32)
+                pose = ref.update_pose(pose, speed, pv, sv, 1.0 / 104.0)
+            assert np.array_equal(got, pose), k
+        if k == 2:                                                    # the same through feed()
+            rp.feed(L[k].numpy(), R[k].numpy(), float(ts[k]), gyro_deg_s=gyro, images_read=2)
+            pose = ref.pose().astype(np.float32)
+            for g in gyro[:min(5, int(np.float32(104.0) * np.float32(2 / 30.0)))]:
+                speed = np.zeros(6, np.float32)
+                speed[3:] = (g.astype(np.float64) / 180.0 * math.pi).astype(np.float32)
+                pose = ref.update_pose(pose, speed, pv, sv, 1.0 / 104.0)
+            ref.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        else:
+            rp.feed(L[k].numpy(), R[k].numpy(), float(ts[k]))
+            ref.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+        assert np.array_equal(rp.slam.get_frame().pose, ref.pose()), k

@@ -13,9 +13,13 @@ bench.main()
 out = (C.c_ulonglong * 16)()
 assert hip_lib.lib().svo_debug_klt_phases(out) == 0
 v = list(out)
-waves, total = max(v[8], 1), max(sum(v[:5]), 1)
+waves, total = max(v[8], 1), max(sum(v[:5]) + v[5] + v[6] + v[7] + v[11] + v[12] + v[13], 1)
 names = ["prologue", "template (requested or built)", "search tile staged (+ loads in flight)", "iterations", "error pass"]
 print(f"klt_track_kernel: {waves} wavefronts, {v[10] / waves:.1f} iterations and {v[9] / waves:.2f} tile stagings each,"
       f" {total / waves:.0f} ticks of s_memtime per wavefront", file=sys.stderr)
 for n_, c in zip(names, v[:5]):
     print(f"  {n_:40s} {c / waves:9.0f} ticks  {100.0 * c / total:5.1f} %", file=sys.stderr)
+if any(v[i] for i in (5, 6, 7, 11, 12, 13)):        # builds with the diagnostic waits: the two memory phases split up
+    for n_, i in (("level addresses", 5), ("wait: stored flag", 6), ("wait: header", 7), ("wait: template", 11),
+                  ("iteration 0 up to the tile's staging", 12), ("tile loads + LDS stores", 13)):
+        print(f"    {n_:38s} {v[i] / waves:9.0f} ticks", file=sys.stderr)
