@@ -284,7 +284,7 @@ def main():
                          "value = median")
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
     ap.add_argument("--seqs", type=int, default=None,
-                    help="sequences per GPU (default 2048 = eight groups of 256 on eight streams; hd: 256)")
+                    help="sequences per GPU (default 2048 = eight groups of 256 on eight streams; hd: 512 = eight groups of 64)")
     ap.add_argument("--loops", type=int, default=None,
                     help="rendered camera loops per GPU (default 128; hd: 16); ctx sequence s plays loop s %% loops, "
                          "sequences that share a loop enter it at different frames")
@@ -320,7 +320,7 @@ def main():
     hd = args.config == "hd"
     K, Wm, reps = args.steps, max(args.warmup, 1), max(args.repeats, 1)
     n_steps = Wm + reps * K
-    B = args.seqs or (256 if hd else 2048)
+    B = args.seqs or (512 if hd else 2048)
     n_loops = min(B, args.loops or (16 if hd else 128))
     nF = args.loop_frames or (48 if hd else LOOP_FRAMES)
     plan = loop_plan(B, n_loops, nF)

@@ -564,18 +564,6 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         }
         float D = A11 * A22 - A12 * A12;
         D = 1.f / D;
-#ifdef SVO_KLT_PREFETCH
-        // (experiment) touch the next level's template and search tile now: one byte per 128 bytes of the record, one per
-        // row of the tile around twice the current position; they arrive in L2 while this level iterates
-        int pf0 = 0, pf1 = 0;
-        if (level > 0 && tmpl_base && kpi < tmpl_cap) {
-            SVO_GP(const uint8_t) nrec = (SVO_GP(const uint8_t))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level - 1) * KltTmpl<NPAIR>::BYTES);
-            if (tid * 128 < KltTmpl<NPAIR>::BYTES) pf0 = nrec[tid * 128];
-            const ImgView Jn = a.cur[level - 1];
-            const int qx = cv_floor(nx * 2.f - halfWin) - KLT_MARGIN, qy = cv_floor(ny * 2.f - halfWin) - KLT_MARGIN + tid;
-            if (tid < TJ && qx >= 0 && qx + TJ + 8 <= Jn.w && qy >= 0 && qy < Jn.h) pf1 = Jn.g()[M24(qy, Jn.stride) + qx + 24];
-        }
-#endif
         nextx -= halfWin; nexty -= halfWin;
         float prevDx = 0, prevDy = 0;
         int tx0 = 0, ty0 = 0;
@@ -662,9 +650,6 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             }
             prevDx = dx; prevDy = dy;
         }
-#ifdef SVO_KLT_PREFETCH
-        asm volatile("" ::"v"(pf0), "v"(pf1));
-#endif
         KLT_PHASE(3);                              // iterations
 
         if (status && level == 0) {

@@ -1325,14 +1325,19 @@ svo_ctx::Worker* ctx_locate(svo_ctx* c, int seq, int* local) {
 extern "C" int svo_ctx_create(const svo_camera_settings* cam, int width, int height, int n_sequences,
                               int device, svo_ctx** out) {
     if (!cam || !out || n_sequences < 1) return svo_set_error(SVO_ERR_INVALID, "svo_ctx_create: bad arguments");
-    // SVO_GROUPS: number of independently driven groups. Default: groups of ~256 sequences, at least
+    // SVO_GROUPS: number of independently driven groups. Default: groups of ~256 sequences — fewer per group
+    // when a sequence carries many keypoints (131072 / keypoint capacity, at least 32: 64 at the 1920x1080
+    // configuration, whose alignment launch is as slow as its slowest sequence whatever the group's size:
+    // 256 sequences, frames/s: 1 group 12.1 K, 2 13.2 K, 4 14.1 K, 8 13.2 K; 512 in 8 18.2 K) —, at least
     // two from 64 sequences on, and one fewer than the hardware queues the HIP runtime uses
     // (GPU_MAX_HW_QUEUES, default 4): streams beyond that share a queue and serialise. Measured on
     // MI355X, 752x480, frames/s: 768 sequences 149 K as 3 groups, 106 K as 4, 119 K as 6 with 4
     // queues; with GPU_MAX_HW_QUEUES=8: 768 / 3 groups 154 K, 1024 / 4 162 K, 1536 / 6 170 K.
     int hwq = 4;
     if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) hwq = std::max(2, std::atoi(e));
-    int G = n_sequences >= 64 ? std::max(2, (n_sequences + 128) / 256) : 1;
+    const int kp_cap = (cam->grid_width > 0 && cam->grid_height > 0 ? (width / cam->grid_width) * (height / cam->grid_height) : 0) + 64;
+    const int per_group = std::max(32, std::min(256, 131072 / std::max(kp_cap, 1)));
+    int G = n_sequences >= 64 ? std::max(2, (n_sequences + per_group / 2) / per_group) : 1;
     G = std::min(G, hwq - 1);
     if (const char* e = std::getenv("SVO_GROUPS")) G = std::atoi(e);
     G = std::max(1, std::min(G, std::min(n_sequences, 16)));

@@ -1,7 +1,7 @@
 #!/bin/bash
-# BASELINE config 3 (1920x1080, 43x24 grid, 5-level SIA pyramid): 256 sequences, CPU legs on, kernel stats
+# BASELINE config 3 (1920x1080, 43x24 grid, 5-level SIA pyramid): 512 sequences in eight groups of 64, CPU legs on, kernel stats
 S=$(date +%s)
-timeout -k 10 900 python bench.py --config hd --seqs 256 --steps 16 --warmup 4 --repeats 2 --no-extras > gpurun_out/r03_c3_hd_bench.json 2> gpurun_out/r03_c3_hd_bench.err; echo "rc=$? $(( $(date +%s) - S )) s"; tail -2 gpurun_out/r03_c3_hd_bench.err
+timeout -k 10 900 python bench.py --config hd --seqs 512 --steps 16 --warmup 4 --repeats 2 --no-extras > gpurun_out/r03_c3_hd_bench.json 2> gpurun_out/r03_c3_hd_bench.err; echo "rc=$? $(( $(date +%s) - S )) s"; tail -2 gpurun_out/r03_c3_hd_bench.err
 python - <<'PY'
 import json
 j = json.load(open("gpurun_out/r03_c3_hd_bench.json"))
@@ -11,7 +11,7 @@ print({k: round(v, 3) for k, v in j["roofline"]["stage_ms_per_launch"].items()},
 PY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/rp_hd
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_hd -- python3 bench.py --config hd --seqs 256 --steps 8 --warmup 4 --repeats 1 --no-extras --no-cpu-baseline > gpurun_out/r03_c3_hd_bench_under_rocprof.json 2> /tmp/hd_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_hd -- python3 bench.py --config hd --seqs 512 --steps 8 --warmup 4 --repeats 1 --no-extras --no-cpu-baseline > gpurun_out/r03_c3_hd_bench_under_rocprof.json 2> /tmp/hd_kt.err
 find /tmp/rp_hd -name "*kernel_stats.csv" -exec cp {} gpurun_out/r03_c3_hd_kernel_stats.csv \;
 head -12 gpurun_out/r03_c3_hd_kernel_stats.csv | cut -c1-140
 # the pyramid stage alone: one sequence group
