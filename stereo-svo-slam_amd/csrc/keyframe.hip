@@ -413,7 +413,9 @@ __global__ __launch_bounds__(1024) void kf_select_merge_kernel(const MergeArgs* 
 }
 
 void launch_select_merge(const MergeArgs* d_args, int batch, int max_cells, hipStream_t stream) {
-    hipLaunchKernelGGL(kf_select_merge_kernel, dim3(batch), dim3(max_cells <= 512 ? 256 : 1024), 0, stream, d_args);
+    static const int env_threads = getenv("SVO_MERGE_THREADS") ? atoi(getenv("SVO_MERGE_THREADS")) : 0;   // (experiments)
+    const int threads = env_threads >= 64 && env_threads <= 1024 && env_threads % 64 == 0 ? env_threads : (max_cells <= 512 ? 256 : 1024);
+    hipLaunchKernelGGL(kf_select_merge_kernel, dim3(batch), dim3(threads), 0, stream, d_args);
 }
 
 // ------------------------------------------------------------------- init

@@ -28,10 +28,13 @@ namespace svo {
 
 constexpr int KLT_MAX_WIN = 35;                        // (the entry points reject larger windows)
 static_assert(KLT_MAX_WIN + 1 <= 36, "largest kernel shape");
+// Pixels the window may drift before the search tile is staged again. The result does not depend on it (exact
+// integer sums from whatever tile holds the window); 4 instead of 6 makes the 32-column shape's tile 8.1 instead of
+// 9.3 KB — LDS is what the window kernels of a step compete for — and a level still stages once (+0.9 % frames/s).
 #ifndef SVO_KLT_MARGIN
-#define SVO_KLT_MARGIN 6
+#define SVO_KLT_MARGIN 4
 #endif
-constexpr int KLT_MARGIN = SVO_KLT_MARGIN;        // pixels the window may drift before the search tile is staged again
+constexpr int KLT_MARGIN = SVO_KLT_MARGIN;
 // The search tile is kept as 16-bit values (pixel << 7) in TWO copies, the second shifted by one pixel:
 // the bilinear pair (p[x], p[x+1]) of any column x is then ONE aligned ds_read_b32 (copy x & 1, dword
 // x >> 1) that already is the int16 pair v_dot2 wants — no byte loads, no packing in the iteration.
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         float prevDx = 0, prevDy = 0;
         int tx0 = 0, ty0 = 0;
         bool have_tile = false;
-        const int TW = (TJ + 3 + 3) & ~3;            // tile columns: covers the 6 px margin from any dword phase
+        const int TW = (TJ + 3 + 3) & ~3;            // tile columns: covers the margin from any dword phase
 
         // stage the search tile [tx0, tx0+TW) x [ty0, ty0+TJ) around the window at (cx, cy)
         auto load_tile = [&](int cx, int cy) {

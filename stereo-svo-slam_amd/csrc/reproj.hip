@@ -172,12 +172,13 @@ __device__ void reproj_gradient(const ReprojArgs& a, const RpKps& kp, int n, con
     exponential_map(twist, grad);                  // not rotated (pose_refinement.cpp:398-411)
 }
 
-// (diagnostic builds: -DSVO_RP_OCC=n caps the registers at 512/n per lane)
-#ifdef SVO_RP_OCC
-#define RP_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_RP_OCC)))
-#else
-#define RP_OCC_ATTR
+// Registers are capped at 512 / SVO_RP_OCC per lane. 2: the one-wave shape wanted 259 (5 go to scratch), and a
+// wavefront that holds 264 of a SIMD's 512 registers leaves room for one KLT wavefront beside it, one that holds
+// 256 for two (+0.4 % frames/s on top of the smaller KLT tile, profiles/r03_ab_steps.txt).
+#ifndef SVO_RP_OCC
+#define SVO_RP_OCC 2
 #endif
+#define RP_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_RP_OCC)))
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) RP_OCC_ATTR void reproj_gn_kernel(const ReprojArgs* __restrict__ args, int cap) {
     constexpr int T = 64 * WAVES;
