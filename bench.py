@@ -537,6 +537,9 @@ def main():
                    "fps_tracked_frames_only_note": "non-keyframe frames / (time x (1 - share of the keyframe stage in the "
                                                    "groups' HIP-event time)): an estimate; the single-sequence leg measures it directly",
                    "sequence_groups": G,
+                   "image_sets_allocated": int(t1.image_sets), "keyframes_created": int(t1.keyframes),
+                   "image_sets_note": "image sets (pyramids of one frame) the ctx allocated in the whole run, beside the keyframes it "
+                                      "created: a keyframe's images are released once no tracked keypoint comes from it",
                    "gn_gradient_calls_per_frame": counters["n_grad"] / max(counters["frames"], 1),
                    "gn_cost_calls_per_frame": counters["n_cost"] / max(counters["frames"], 1),
                    "single_sequence": single, "host_input": host_input, "c3": c3,

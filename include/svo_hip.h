@@ -214,7 +214,8 @@ typedef struct svo_totals {
     int64_t launches;           /* frame sets processed, summed over groups: stage_ms / launches =
                                    mean duration of one stage launch                */
     int32_t n_groups;           /* independently driven sequence groups of the ctx */
-    int32_t reserved;
+    int32_t image_sets;         /* image sets (pyramids of one frame) allocated so far, summed over groups: bounded by
+                                   the keyframes whose keypoints are still tracked (their images are released after that) */
 } svo_totals;
 int svo_get_totals(svo_ctx *ctx, svo_totals *out);
 int svo_ctx_enable_timing(svo_ctx *ctx, int on);

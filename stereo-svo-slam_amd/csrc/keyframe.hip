@@ -65,7 +65,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
     const CompactArgs& a = args[blockIdx.x];
     if (a.enable && !*G(a.enable)) return;
     __shared__ int s_wave[16];
+    __shared__ int s_min_kf;
+    __shared__ unsigned s_live[2];
     const int tid = threadIdx.x;
+    if (tid == 0) { s_min_kf = INT_MAX; s_live[0] = s_live[1] = 0u; }   // (the scan's barriers stand between this and the atomics below)
     const int n = *G(a.src.n);
     const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
     const int i0 = tid * per, i1 = min(n, i0 + per);
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
     }
     int total;
     int pos = block_exclusive_scan(cnt, s_wave, total);
+    int min_kf = INT_MAX;
     for (int i = i0; i < i1; i++) {
         const uint32_t f = G(a.src.flags)[i];
         bool keep;
@@ -94,9 +98,24 @@ __global__ __launch_bounds__(1024) void compact_kernel(const CompactArgs* __rest
             keep = !((k.x < 0) || (k.y < 0) || (k.x > a.width) || (k.y > a.height) ||
                      (f & SVO_IGNORE_COMPLETELY) || (f & SVO_IGNORE_DURING_REFINEMENT));
         }
-        if (keep) copy_kp(a.dst, pos++, a.src, i);
+        if (keep) {
+            copy_kp(a.dst, pos++, a.src, i);
+            min_kf = min(min_kf, G(a.src.kf_id)[i]);
+        }
     }
     if (tid == 0) *G(a.dst.n) = total;
+    if (a.min_kf) {                            // (uniform) which keyframes the frame's keypoints still refer to
+        if (min_kf != INT_MAX) atomicMin(&s_min_kf, min_kf);
+        __syncthreads();
+        const int base = s_min_kf;
+        for (int i = i0; i < i1; i++) {
+            if (G(a.src.flags)[i] & SVO_IGNORE_COMPLETELY) continue;      // (mode 0: exactly the keypoints kept above)
+            const int j = G(a.src.kf_id)[i] - base;
+            if (j >= 0 && j < 64) atomicOr(&s_live[j >> 5], 1u << (j & 31));
+        }
+        __syncthreads();
+        if (tid == 0) { G(a.min_kf)[0] = base; G(a.min_kf)[1] = (int)s_live[0]; G(a.min_kf)[2] = (int)s_live[1]; }
+    }
     if (a.zero)
         for (int i = tid; i < a.zero_count; i += blockDim.x) G(a.zero)[i] = 0;
 }

@@ -163,6 +163,8 @@ struct FrameResult {            // device -> host, one per sequence and frame
     float pose_refined[6];
     float sia_cost, reproj_cost;
     int inside, overflow, kf_n, old_count;
+    int min_kf;                 // smallest origin-keyframe id of the frame's keypoints (compact_kernel) ...
+    unsigned live_kf[2];        // ... and which of the 64 keyframes from there on still have keypoints in the frame
     svo_gn_trace sia_trace[SVO_MAX_PYRAMID_LEVELS];
     svo_gn_trace reproj_trace;
 };
@@ -190,6 +192,7 @@ struct Seq {
     uint8_t* tmpl_valid = nullptr;   // their "stored" flags
     KfDev* d_kfs = nullptr;
     std::vector<KfHost> kfs;
+    int kfs_retired = 0;             // keyframes [0, kfs_retired) have given their image sets back
     DetCell* det = nullptr; int* n_det = nullptr;
     DetCell* sel = nullptr; int* sel_level = nullptr; int* sel_cell = nullptr; int* occupied = nullptr;
     uint32_t* color_lcg = nullptr;
@@ -313,6 +316,8 @@ struct svo_group {
     int tmpl_kf = 0, tmpl_cap = 0;
     size_t tmpl_block_bytes = 0, tmpl_valid_bytes = 0;
     svo_totals totals;
+    bool retire_kf_images = true;    // SVO_KEEP_KEYFRAME_IMAGES=1: keep every keyframe's image set (the reference's behaviour)
+    int image_sets = 0;              // image sets allocated so far
     HostPool* pool = nullptr;
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // SVO_HOST_TIMING diagnostic: host phases of a step
     long host_steps = 0;
@@ -373,6 +378,7 @@ void image_set_layout(svo_group* c, ImageSet* s, size_t* offs_left, size_t* offs
 
 int new_image_set(svo_group* c, ImageSet** out) {
     ImageSet* s = new ImageSet();
+    c->image_sets++;
     size_t offs_left[SVO_MAX_PYRAMID_LEVELS], offs_lk[SVO_LK_LEVELS], off_right;
     image_set_layout(c, s, offs_left, offs_lk, &off_right);
     if (c->set_slabs.empty()) {
@@ -554,6 +560,7 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     c->cap = (int)align_up((size_t)(2 * cells + 128), 64);
     c->rec_cap = (int)align_up((size_t)c->cap, 512);   // whole passes of the widest alignment workgroup
     c->max_kf = 4096;
+    if (const char* e = std::getenv("SVO_KEEP_KEYFRAME_IMAGES")) c->retire_kf_images = std::atoi(e) == 0;
     // usable LK levels (cv::buildOpticalFlowPyramid stops at levels not larger than the window)
     {
         int n = SVO_LK_LEVELS, w = width, h = height;
@@ -706,7 +713,8 @@ static int grp_destroy(svo_group* c) {
         std::vector<ImageSet*> all(q.free_sets);
         if (q.cur_set) all.push_back(q.cur_set);
         if (q.prev_set) all.push_back(q.prev_set);
-        for (auto& k : q.kfs) all.push_back(k.set);
+        for (auto& k : q.kfs)
+            if (k.set) all.push_back(k.set);
         std::sort(all.begin(), all.end());
         all.erase(std::unique(all.begin(), all.end()), all.end());
         for (ImageSet* s : all) delete s;
@@ -905,6 +913,7 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             CompactArgs* ca = args_at<CompactArgs>(c, c->off_compact, slot);
             std::memset(ca, 0, sizeof(*ca));
             ca->src = q.kps[q.cur]; ca->dst = q.kps[q.cur ^ 1]; ca->mode = 0;
+            ca->min_kf = &dr->min_kf;
             q.cur ^= 1;
             const KpsDev& k = q.kps[q.cur];
             SiaArgs* sa = args_at<SiaArgs>(c, c->off_sia, slot);
@@ -1055,6 +1064,29 @@ static int grp_new_images_impl(svo_group* c, const uint8_t* const* left, const u
             if (first) std::memset(k.pose, 0, sizeof(k.pose));
             else std::memcpy(k.pose, r.pose_refined, sizeof(k.pose));
         }
+        // Keyframe images are only read for keypoints that came from that keyframe (KLT builds a template from
+        // them when the cache has none). The frame's keypoints — kept by the compaction at its start, plus what a
+        // keyframe created in this frame adds — refer to keyframes r.min_kf and younger and, of the next 64, to
+        // those whose bit is set in r.live_kf: the others hand their image sets back to the sequence's free
+        // list, so memory stays bounded by the keyframes still in use
+        // instead of growing with every keyframe (the reference keeps them all). Nothing else of a keyframe goes:
+        // its keypoint arrays, pose and table record stay for the depth filter and the getters.
+        if (!first && c->retire_kf_images) {
+            const int newest = (int)q.kfs.size() - 1;                  // (never the newest: a keyframe made in this frame)
+            const int upto = std::min(r.min_kf, newest);
+            for (; q.kfs_retired < upto; q.kfs_retired++) {
+                KfHost& old = q.kfs[q.kfs_retired];
+                release_set(q, old.set);
+                old.set = nullptr;
+            }
+            for (int j = 0; j < 64 && r.min_kf < newest && r.min_kf + j < newest; j++) {
+                KfHost& old = q.kfs[r.min_kf + j];
+                if (old.set && !((r.live_kf[j >> 5] >> (j & 31)) & 1u)) {
+                    release_set(q, old.set);
+                    old.set = nullptr;
+                }
+            }
+        }
         q.n_host = c->h_n[2 * s + q.cur];
         svo_frame_stats& st = q.stats;
         std::memset(&st, 0, sizeof(st));
@@ -1103,6 +1135,7 @@ static int grp_new_images(svo_group* c, const uint8_t* const* left, const uint8_
 static int grp_get_totals(svo_group* c, svo_totals* out) {
     if (!c || !out) return svo_set_error(SVO_ERR_INVALID, "svo_get_totals: bad arguments");
     *out = c->totals;
+    out->image_sets = c->image_sets;
     return SVO_OK;
 }
 
@@ -1464,6 +1497,7 @@ extern "C" int svo_get_totals(svo_ctx* c, svo_totals* out) {
         for (int i = 0; i < 8; i++) out->stage_ms[i] += t.stage_ms[i];
         out->wall_ms = std::max(out->wall_ms, t.wall_ms);
         out->launches += t.launches;
+        out->image_sets += t.image_sets;
     }
     out->n_groups = (int)c->workers.size();
     return SVO_OK;

@@ -32,6 +32,8 @@ struct CompactArgs {
     const int* enable; // optional device predicate
     int* zero;         // optional: zero_count ints set to 0 (the detection counters of the keyframe that follows)
     int zero_count;
+    int* min_kf;       // optional: [3] smallest origin-keyframe id among the keypoints kept (INT_MAX: none kept), then a 64-bit
+                       // mask (low word first): bit j set = some kept keypoint comes from keyframe min + j (younger ones: not reported)
 };
 void launch_compact(const CompactArgs* d_args, int batch, int cap, hipStream_t stream);
 

@@ -45,7 +45,7 @@ class Totals(C.Structure):
     _fields_ = [("frames", C.c_int64), ("keyframes", C.c_int64), ("keypoints", C.c_int64),
                 ("gn_gradient_calls", C.c_int64), ("gn_cost_calls", C.c_int64),
                 ("stage_ms", C.c_double * 8), ("wall_ms", C.c_double),
-                ("launches", C.c_int64), ("n_groups", C.c_int32), ("reserved", C.c_int32)]
+                ("launches", C.c_int64), ("n_groups", C.c_int32), ("image_sets", C.c_int32)]
 
 
 class Frame:

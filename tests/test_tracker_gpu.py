@@ -460,3 +460,46 @@ def test_borrowed_device_frames_equal_copied_ones():
         assert np.array_equal(fa.info, fb.info)
     assert a.num_keyframes(0) == b.num_keyframes(0) >= 2
     a.close(); b.close()
+
+
+def test_keyframe_images_are_released_when_no_keypoint_needs_them(monkeypatch):
+    """A keyframe's image set is only read for keypoints that came from it; once the frame's keypoints refer to
+    younger keyframes only it goes back to the sequence's free list (the reference keeps every keyframe's
+    images: memory that grows with the run). Same frames, keyframes and trajectory as with
+    SVO_KEEP_KEYFRAME_IMAGES=1 and as the oracle's; fewer image sets allocated."""
+    n = 160                                       # a steady turn (0.86 deg per frame): what a keyframe saw leaves the image for good
+    cfg = dict(synth.CONFIGS["euroc"])
+    scene = synth.Scene(0, "cuda")
+    poses = np.zeros((n, 6), np.float32)
+    poses[:, 4] = 0.015 * np.arange(n)
+    seeds = 7919 + 2 * np.arange(n)
+    L = [x.cpu() for x in synth.render_frames_gpu(scene, cfg, poses, False, 1.0, seeds)]
+    R = [x.cpu() for x in synth.render_frames_gpu(scene, cfg, poses, True, 1.0, seeds + 1)]
+    ts = np.arange(n, dtype=np.float32) / 20.0
+    ref = O.Slam(util.oracle_camera(cfg))
+    runs = {}
+    for keep in ("0", "1"):
+        monkeypatch.setenv("SVO_KEEP_KEYFRAME_IMAGES", keep)
+        gpu = StereoSlam(cfg, cfg["width"], cfg["height"])
+        frames = []
+        for k in range(n):
+            gpu.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+            if keep == "0":
+                ref.new_image(L[k].numpy(), R[k].numpy(), float(ts[k]))
+                ok2, ok3, oinfo = ref.keypoints()
+                _compare_frame(f"frame {k}", gpu.get_frame(), ok2, ok3, oinfo, ref.pose(), 0.0)
+            f = gpu.get_frame()
+            frames.append((f.pose.copy(), f.kps2d.copy(), f.kps3d.copy(), f.info.copy()))
+        runs[keep] = (frames, gpu.num_keyframes(), gpu.totals().image_sets, gpu.get_trajectory().copy())
+        for kid in range(gpu.num_keyframes()):              # every keyframe is still served, images or not
+            k2, k3, info, pose = ref.keyframe(kid)
+            g = gpu.get_keyframe(kid)
+            assert np.array_equal(g.info["color"], info["color"]) and np.max(np.abs(g.pose - pose)) < 1e-4
+        gpu.close()
+    (fa, kfa, sets_a, ta), (fb, kfb, sets_b, tb) = runs["0"], runs["1"]
+    assert kfa == kfb == ref.num_keyframes() and kfa >= 5, kfa
+    assert np.array_equal(ta, tb)
+    for a, b in zip(fa, fb):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    print(f"{kfa} keyframes in {n} frames: {sets_a} image sets allocated with release, {sets_b} without")
+    assert sets_b >= kfa + 2 and sets_a <= sets_b - 2, (sets_a, sets_b)
