@@ -664,14 +664,17 @@ static int grp_create(const svo_camera_settings* cam, int width, int height, int
     }
     if ((rc = grow_kf_slabs(c, std::max(2 * B, 32)))) return rc;   // the first keyframes never allocate
     {
-        // KLT template cache: SVO_KLT_CACHE_KF keyframes per sequence (default 4, 0 = off), as many as fit a
-        // third of the free device memory. A keypoint index beyond tmpl_cap (more points than grid cells + 64 in
-        // the frame that made the keyframe) is tracked without the cache.
-        int K = 4;
-        if (const char* e = std::getenv("SVO_KLT_CACHE_KF")) K = std::max(0, std::min(std::atoi(e), 64));
+        // KLT template cache: SVO_KLT_CACHE_KF keyframes per sequence (default 8 while a keyframe's block stays below
+        // 8 MB, else 4; 0 = off), as many as fit a third of the free device memory. On closed camera loops every
+        // keyframe keeps keypoints in view, and those of keyframes that have left the ring build their templates
+        // on every frame: 8 instead of 4 blocks per sequence are +0.8 % frames/s at C2 (profiles/r03_ab_steps.txt).
+        // A keypoint index beyond tmpl_cap (more points than grid cells + 64 in the frame that made the keyframe)
+        // is tracked without the cache.
         const int cells_ = (width / cam->grid_width) * (height / cam->grid_height);
         c->tmpl_cap = std::min(c->cap, cells_ + 64);
         c->tmpl_block_bytes = align_up((size_t)c->tmpl_cap * SVO_LK_LEVELS * klt_template_bytes(cam->window_size_opt_flow), 256);
+        int K = c->tmpl_block_bytes <= ((size_t)8 << 20) ? 8 : 4;
+        if (const char* e = std::getenv("SVO_KLT_CACHE_KF")) K = std::max(0, std::min(std::atoi(e), 64));
         c->tmpl_valid_bytes = align_up((size_t)c->tmpl_cap * SVO_LK_LEVELS, 256);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));

@@ -327,7 +327,7 @@ def test_klt_template_cache_changes_nothing(monkeypatch):
     """The KLT template cache (a keyframe's templates kept in HBM for the sequence's last keyframes)
     only replaces recomputation by a load: with the cache off, with a ring of one keyframe (every
     new keyframe evicts the previous one, whose points are tracked from the images again) and with
-    the default ring of four, every frame of a sequence with several keyframes is the same."""
+    a ring of four (the default is eight), every frame of a sequence with several keyframes is the same."""
     n_frames = 36
     cfg, L, R, poses, ts = synth.make_sequence("tiny", n_frames, 2, device="cpu", motion_scale=4.0)
     runs = {}
