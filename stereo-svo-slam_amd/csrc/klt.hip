@@ -266,34 +266,53 @@ __device__ inline void stage_tile(uint8_t* tile, const ImgView& im, int x0, int 
 // two copies, copy 0 from column 0 and copy 1 from column 1 (GEO::J2S dwords per row, GEO::J2COPY
 // dwords apart). Inside the image: one dword per lane, 16 lanes per row (a DPP row: the next
 // dword's first pixel comes from the neighbouring lane); else byte by byte with BORDER_REFLECT_101.
+// The in-image case in two halves, so that a caller can have the loads in flight while it does something else.
+__device__ inline bool tile_in_image(const ImgView& im, int x0, int y0, int nq, int rows) {
+    return x0 >= 0 && y0 >= 0 && x0 + 4 * nq <= im.w && y0 + rows <= im.h &&
+           (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
+}
+template <class GEO>
+struct KltTileRegs {
+    static constexpr int RPP = KLT_THREADS / 16;                     // rows per pass
+    static constexpr int NP = (GEO::TJROWS + RPP - 1) / RPP;
+    uint32_t v[NP];
+};
+template <class GEO>
+__device__ inline void tile_j2_load(KltTileRegs<GEO>& t, const ImgView& im, int x0, int y0, int nq, int rows) {
+    constexpr int RPP = KltTileRegs<GEO>::RPP, NP = KltTileRegs<GEO>::NP;
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    const uint8_t* g = im.g() + M24(y0 + r0, im.stride) + x0 + 4 * min(c4, nq - 1);
+#pragma unroll
+    for (int u = 0; u < NP; u++)
+        t.v[u] = (r0 + u * RPP < rows) ? *reinterpret_cast<const uint32_t*>(g + M24(u * RPP, im.stride)) : 0u;
+}
+template <class GEO>
+__device__ inline void tile_j2_store(uint32_t* tile, const KltTileRegs<GEO>& tr, int nq, int rows) {
+    constexpr int RPP = KltTileRegs<GEO>::RPP, NP = KltTileRegs<GEO>::NP, KLT_J2S = GEO::J2S, KLT_J2COPY = GEO::J2COPY;
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    SVO_LDS(uint32_t)* t0 = (SVO_LDS(uint32_t)*)tile + r0 * KLT_J2S + 2 * c4;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const uint32_t v = tr.v[u];
+        const uint32_t e7 = (v & 0x00ff00ffu) << 7, o7 = ((v >> 8) & 0x00ff00ffu) << 7;   // (p0, p2), (p1, p3), each << 7
+        const uint32_t ne7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e7, 0x101 /* row_shl:1 */, 0xF, 0xF, false);
+        if (c4 < nq && r0 + u * RPP < rows) {
+            SVO_LDS(uint32_t)* t = t0 + u * RPP * KLT_J2S;
+            t[0] = __builtin_amdgcn_perm(o7, e7, 0x05040100u);                 // (p0, p1)
+            t[1] = __builtin_amdgcn_perm(o7, e7, 0x07060302u);                 // (p2, p3)
+            t[KLT_J2COPY] = __builtin_amdgcn_perm(e7, o7, 0x07060100u);        // (p1, p2)
+            t[KLT_J2COPY + 1] = __builtin_amdgcn_perm(ne7, o7, 0x05040302u);   // (p3, p4): p4 from the next lane (unused in the last column)
+        }
+    }
+}
 template <class GEO>
 __device__ inline void stage_tile_j2(uint32_t* tile, const ImgView& im, int x0, int y0, int nq, int rows) {
-    constexpr int KLT_TJROWS = GEO::TJROWS, KLT_J2S = GEO::J2S, KLT_J2COPY = GEO::J2COPY;
+    constexpr int KLT_J2S = GEO::J2S, KLT_J2COPY = GEO::J2COPY;
     const int tid = threadIdx.x;
-    const bool fast = x0 >= 0 && y0 >= 0 && x0 + 4 * nq <= im.w && y0 + rows <= im.h &&
-                      (((reinterpret_cast<uintptr_t>(im.data) | (uintptr_t)im.stride) & 3) == 0);
-    if (fast) {
-        constexpr int RPP = KLT_THREADS / 16;                        // rows per pass
-        constexpr int NP = (KLT_TJROWS + RPP - 1) / RPP;
-        const int c4 = tid & 15, r0 = tid >> 4;
-        const uint8_t* g = im.g() + M24(y0 + r0, im.stride) + x0 + 4 * min(c4, nq - 1);
-        uint32_t v[NP];
-#pragma unroll
-        for (int u = 0; u < NP; u++)
-            v[u] = (r0 + u * RPP < rows) ? *reinterpret_cast<const uint32_t*>(g + M24(u * RPP, im.stride)) : 0u;
-        SVO_LDS(uint32_t)* t0 = (SVO_LDS(uint32_t)*)tile + r0 * KLT_J2S + 2 * c4;
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            const uint32_t e7 = (v[u] & 0x00ff00ffu) << 7, o7 = ((v[u] >> 8) & 0x00ff00ffu) << 7;   // (p0, p2), (p1, p3), each << 7
-            const uint32_t ne7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e7, 0x101 /* row_shl:1 */, 0xF, 0xF, false);
-            if (c4 < nq && r0 + u * RPP < rows) {
-                SVO_LDS(uint32_t)* t = t0 + u * RPP * KLT_J2S;
-                t[0] = __builtin_amdgcn_perm(o7, e7, 0x05040100u);                 // (p0, p1)
-                t[1] = __builtin_amdgcn_perm(o7, e7, 0x07060302u);                 // (p2, p3)
-                t[KLT_J2COPY] = __builtin_amdgcn_perm(e7, o7, 0x07060100u);        // (p1, p2)
-                t[KLT_J2COPY + 1] = __builtin_amdgcn_perm(ne7, o7, 0x05040302u);   // (p3, p4): p4 from the next lane (unused in the last column)
-            }
-        }
+    if (tile_in_image(im, x0, y0, nq, rows)) {
+        KltTileRegs<GEO> tr;
+        tile_j2_load<GEO>(tr, im, x0, y0, nq, rows);
+        tile_j2_store<GEO>(tile, tr, nq, rows);
     } else {
         const int tcol = tid & 63, trow0 = tid >> 6;
         SVO_LDS(uint16_t)* t16 = (SVO_LDS(uint16_t)*)tile;
@@ -323,13 +342,8 @@ __device__ inline void stage_tile_j2(uint32_t* tile, const ImgView& im, int x0, 
 // One wavefront per keypoint (KLT_THREADS = 64): no cross-wave barrier in the iteration, and a
 // single-wave workgroup finds a slot while the Gauss-Newton kernels of other sequence groups hold
 // most of a CU's registers (+3 % frames/s against 128 threads on the 768-sequence bench).
-#ifdef SVO_KLT_WAVES_PER_EU
-#define KLT_OCC_ATTR __attribute__((amdgpu_waves_per_eu(SVO_KLT_WAVES_PER_EU)))
-#else
-#define KLT_OCC_ATTR
-#endif
 template <int CW>
-__global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(const KltArgs* __restrict__ args) {
+__device__ __forceinline__ void klt_track_body(const KltArgs* __restrict__ args) {
     constexpr int NG = KLT_THREADS / CW;                               // row groups
     constexpr int ROWS = CW;                                            // tap rows to cover (w+1 <= CW)
     constexpr int RPT = (((ROWS + NG - 1) / NG) + 1) & ~1;              // even: rows are kept as pairs
@@ -435,23 +449,52 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             rec = (SVO_GP(uint4))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level) * KltTmpl<NPAIR>::BYTES);
             vflag = G(kfp->tmpl_valid) + kpi * SVO_LK_LEVELS + level;
         }
-        KLT_PHASE(5);                              // (diagnostic split of phase 1: addresses of the level)
-        const bool hit = vflag && *vflag != 0;
-        KLT_PHASE_WAIT(6);                         // ... the "stored" flag has arrived
-        if (hit) {
-            SVO_GP(const KltTmplHeader) hd = (SVO_GP(const KltTmplHeader))(rec + KltTmpl<NPAIR>::TQ * 64);
-            lstate = hd->state; A11 = hd->A11; A12 = hd->A12; A22 = hd->A22; cI1 = hd->cI1; cI2 = hd->cI2;
-            KLT_PHASE_WAIT(7);                     // ... the header
-            if (lstate == KLT_TRACK) {
-                uint4 v[KltTmpl<NPAIR>::TQ];
+        KLT_PHASE(5);                              // (diagnostic split of phase 1: image views and addresses of the level)
+        // A cached level costs memory round trips, not arithmetic (profiles/r03_klt_phases.txt: a third of a
+        // wavefront's life): the "stored" flag, the header, the template and the search tile around the predicted
+        // position do not depend on each other's values, so all four are requested here, before the first is
+        // looked at (until then: flag, then header, then template + tile — three dependent round trips per level).
+        // What a miss does not need is dropped. Alone the kernel takes as long as before — it is not waiting for
+        // memory at 16 wavefronts per CU — but its wavefronts hold their registers and LDS for less time: +0.8 %
+        // frames/s in the mix (eight interleaved pairs, profiles/r03_ab_steps.txt).
+        const int TW = (TJ + 3 + 3) & ~3;            // tile columns: covers the margin from any dword phase
+        int tx0 = 0, ty0 = 0;
+        bool have_tile = false, tile_regs = false;
+        KltTileRegs<GEO> pre;
+        uint4 hq0 = make_uint4(0, 0, 0, 0), hq1 = hq0;
+        uint4 tq[KltTmpl<NPAIR>::TQ];
+        int flag = 0;
+        if (vflag) {
+            flag = *vflag;
+            SVO_GP(const uint4) hd = rec + KltTmpl<NPAIR>::TQ * 64;
+            hq0 = hd[0]; hq1 = hd[1];
 #pragma unroll
-                for (int q = 0; q < KltTmpl<NPAIR>::TQ; q++) v[q] = rec[q * 64 + tid];
-                KLT_PHASE_WAIT(11);                // ... the template (the product code does not wait here)
-                const uint32_t* f = reinterpret_cast<const uint32_t*>(v);
+            for (int q = 0; q < KltTmpl<NPAIR>::TQ; q++) tq[q] = rec[q * 64 + tid];
+            const int px = cv_floor(nextx - halfWin), py = cv_floor(nexty - halfWin);      // where iteration 0 will look
+            const int qx0 = (px - KLT_MARGIN) & ~3, qy0 = py - KLT_MARGIN;
+            if (tile_in_image(J, qx0, qy0, TW >> 2, TJ)) {
+                tile_j2_load<GEO>(pre, J, qx0, qy0, TW >> 2, TJ);
+                tx0 = qx0; ty0 = qy0; tile_regs = true;
+            }
+        }
+        KLT_PHASE_WAIT(6);                         // (diagnostic builds: everything requested above has arrived)
+        const bool hit = flag != 0;
+        if (hit) {
+            static_assert(sizeof(KltTmplHeader) == 32, "two 16-byte loads");
+            lstate = (int)hq0.x; A11 = __uint_as_float(hq0.y); A12 = __uint_as_float(hq0.z); A22 = __uint_as_float(hq0.w);
+            cI1 = __builtin_bit_cast(double, ((unsigned long long)hq1.y << 32) | hq1.x);
+            cI2 = __builtin_bit_cast(double, ((unsigned long long)hq1.w << 32) | hq1.z);
+            if (lstate == KLT_TRACK) {
+                const uint32_t* f = reinterpret_cast<const uint32_t*>(tq);
 #pragma unroll
                 for (int k = 0; k < NPAIR; k++) { tIw[k] = (int)f[k]; tIx[k] = (int)f[NPAIR + k]; tIy[k] = (int)f[2 * NPAIR + k]; }
             }
         } else {
+        tile_regs = false;                           // (the template is built in the tile's LDS: stage it afterwards)
+        // (this path runs once per keypoint and keyframe; opaque copies of the lane's column and first row keep the
+        // compiler from computing its sixteen row addresses before the level loop and holding them through the hot path)
+        int lc_b = lc, y0_b = y0;
+        asm volatile("" : "+v"(lc_b), "+v"(y0_b));
         prevx -= halfWin; prevy -= halfWin;
         const int iprevx = cv_floor(prevx), iprevy = cv_floor(prevy);
         if (iprevx < -win || iprevx >= I.w || iprevy < -win || iprevy >= I.h) {
@@ -469,10 +512,10 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         // Scharr (calcSharrDeriv) at the (w+1)^2 tap positions, sliding down the thread's rows:
         // hd = p[+1]-p[-1], hs = 3(p[-1]+p[+1]) + 10 p[0] per tile row; dx = 3(hd_0+hd_2) + 10 hd_1,
         // dy = hs_2 - hs_0. Zero outside the image.
-        if (lc < DW && row_on) {
-            const int gx = iprevx + lc;
+        if (lc_b < DW && row_on) {
+            const int gx = iprevx + lc_b;
             const bool xin = (unsigned)gx < (unsigned)I.w;
-            const uint32_t pcol = lds_addr(&s_I[y0 * KLT_RS + ox + lc]);
+            const uint32_t pcol = lds_addr(&s_I[y0_b * KLT_RS + ox + lc_b]);
             int p02[RPT + 2], p1[RPT + 2];
             lds_col_nowait<KLT_RS, 1>(pcol, p1);
             lds_pairs<KLT_RS, 0, 2>(pcol, p02);
@@ -482,11 +525,11 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             int hd1 = dot2(as_v2s(p02[1]), kd, 0), hs1 = dot2(as_v2s(p02[1]), ks, M24(p1[1], 10));
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                const int r = y0 + u;
+                const int r = y0_b + u;
                 const int hd2 = dot2(as_v2s(p02[u + 2]), kd, 0), hs2 = dot2(as_v2s(p02[u + 2]), ks, M24(p1[u + 2], 10));
                 const int dx = M24(hd0 + hd2, 3) + M24(hd1, 10);
                 const int dy = hs2 - hs0;
-                if (r < DW) s_d[r * KLT_DW + lc] = (xin && (unsigned)(iprevy + r) < (unsigned)I.h) ? pack16(dx, dy) : 0;
+                if (r < DW) s_d[r * KLT_DW + lc_b] = (xin && (unsigned)(iprevy + r) < (unsigned)I.h) ? pack16(dx, dy) : 0;
                 hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
             }
         }
@@ -496,18 +539,18 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         // (per-thread int32 partials: <= 36 pixels, each product < 2^24)
         int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
         {
-            const int lcs = col_on ? lc : 0;                             // keep idle columns in bounds
+            const int lcs = col_on ? lc_b : 0;                             // keep idle columns in bounds
             // tile row y+1 holds image row iprevy+y
             int ipr[RPT + 1];
-            lds_pairs<KLT_RS, 0, 1>(lds_addr(&s_I[(y0 + 1) * KLT_RS + ox + lcs + 1]), ipr);
-            const int* dcol = &s_d[y0 * KLT_DW + lcs];
+            lds_pairs<KLT_RS, 0, 1>(lds_addr(&s_I[(y0_b + 1) * KLT_RS + ox + lcs + 1]), ipr);
+            const int* dcol = &s_d[y0_b * KLT_DW + lcs];
             int d0 = dcol[0], d1 = dcol[1];
             v2s dxp = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x05040100u));
             v2s dyp = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
             int iv[2], ixv[2], iyv[2];
 #pragma unroll
             for (int u = 0; u < RPT; u++) {
-                const int y = y0 + u;
+                const int y = y0_b + u;
                 d0 = dcol[(u + 1) * KLT_DW]; d1 = dcol[(u + 1) * KLT_DW + 1];
                 const v2s dxp1 = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x05040100u));
                 const v2s dyp1 = as_v2s((int)__builtin_amdgcn_perm((uint32_t)d1, (uint32_t)d0, 0x07060302u));
@@ -569,9 +612,6 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         D = 1.f / D;
         nextx -= halfWin; nexty -= halfWin;
         float prevDx = 0, prevDy = 0;
-        int tx0 = 0, ty0 = 0;
-        bool have_tile = false;
-        const int TW = (TJ + 3 + 3) & ~3;            // tile columns: covers the margin from any dword phase
 
         // stage the search tile [tx0, tx0+TW) x [ty0, ty0+TJ) around the window at (cx, cy)
         auto load_tile = [&](int cx, int cy) {
@@ -602,6 +642,14 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
             for (int u = 0; u <= RPT; u++) jr[u] = (int)q[u * KLT_J2S];
         };
 
+        if (tile_regs) {                             // the tile requested at the level's start
+            __syncthreads();
+            tile_j2_store<GEO>(s_J2, pre, TW >> 2, TJ);
+            __syncthreads();
+            have_tile = true;
+            KLT_COUNT(9, 1);
+            KLT_PHASE(2);
+        }
 #ifndef SVO_KLT_MAXIT
 #define SVO_KLT_MAXIT 30     /* (diagnostic builds count the instructions outside the iteration with 0) */
 #endif
@@ -693,6 +741,20 @@ __global__ __launch_bounds__(KLT_THREADS) KLT_OCC_ATTR void klt_track_kernel(con
         G(a.status)[kp] = (uint8_t)status;
         G(a.err)[kp] = status ? err : INFINITY;   // optical_flow.cpp:46-50
     }
+}
+
+// The two kernel shapes. Registers per wavefront decide how many share a SIMD (512 / n): the 32-column shape
+// is held to 128 (four; a few registers of the template-building path — run once per keypoint and keyframe — go
+// to scratch), the 36-column shape to 256.
+template <int CW>
+__global__ void klt_track_kernel(const KltArgs* __restrict__ args);
+template <>
+__global__ __launch_bounds__(KLT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void klt_track_kernel<32>(const KltArgs* __restrict__ args) {
+    klt_track_body<32>(args);
+}
+template <>
+__global__ __launch_bounds__(KLT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void klt_track_kernel<36>(const KltArgs* __restrict__ args) {
+    klt_track_body<36>(args);
 }
 
 #ifdef SVO_KLT_PHASES

@@ -20,6 +20,7 @@ print(f"klt_track_kernel: {waves} wavefronts, {v[10] / waves:.1f} iterations and
 for n_, c in zip(names, v[:5]):
     print(f"  {n_:40s} {c / waves:9.0f} ticks  {100.0 * c / total:5.1f} %", file=sys.stderr)
 if any(v[i] for i in (5, 6, 7, 11, 12, 13)):        # builds with the diagnostic waits: the two memory phases split up
-    for n_, i in (("level addresses", 5), ("wait: stored flag", 6), ("wait: header", 7), ("wait: template", 11),
-                  ("iteration 0 up to the tile's staging", 12), ("tile loads + LDS stores", 13)):
+    for n_, i in (("level: image views and addresses", 5), ("wait: flag, header, template, tile", 6),
+                  ("(builds before the loads were grouped) header", 7), ("(before ...) template", 11),
+                  ("iteration 0 up to a staging", 12), ("tile loads + LDS stores (restagings only)", 13)):
         print(f"    {n_:38s} {v[i] / waves:9.0f} ticks", file=sys.stderr)
