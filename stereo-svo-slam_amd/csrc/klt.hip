@@ -410,6 +410,9 @@ __device__ __forceinline__ void klt_track_body(const KltArgs* __restrict__ args)
     // template cache of the keyframe (tracker only; null: templates are built every frame)
     const uint8_t* tmpl_base = (a.proj_pose && kfp->tmpl_win == a.win) ? (const uint8_t*)kfp->tmpl : nullptr;
     const int tmpl_cap = kfp->tmpl_cap;
+    // (read here, with the record's other fields, not per level: the keyframe table is touched sparsely, and a scalar
+    // load from it in every level was a round trip to HBM of ~3 K cycles each, profiles/r03_klt_phases.txt)
+    SVO_GP(uint8_t) tmpl_valid = G(kfp->tmpl_valid);
     const int kpi = a.proj_pose ? __builtin_amdgcn_readfirstlane(G(a.kp_index)[kp]) : 0;
     const int maxLevel = min(kfp->n_lk, a.n_cur) - 1;
     const float halfWin = (win - 1) * 0.5f;
@@ -423,7 +426,6 @@ __device__ __forceinline__ void klt_track_body(const KltArgs* __restrict__ args)
 
     KLT_PHASE(0);                                  // prologue: arguments, keyframe record, projection
     for (int level = maxLevel; level >= 0; level--) {
-        const ImgView I = kfp->lk[level];
         const ImgView J = a.cur[level];
         const float lscale = (float)(1. / (1 << level));
         float prevx = ref.x * lscale, prevy = ref.y * lscale;
@@ -447,7 +449,7 @@ __device__ __forceinline__ void klt_track_body(const KltArgs* __restrict__ args)
         SVO_GP(uint8_t) vflag = nullptr;
         if (tmpl_base && kpi < tmpl_cap) {
             rec = (SVO_GP(uint4))(tmpl_base + ((size_t)kpi * SVO_LK_LEVELS + level) * KltTmpl<NPAIR>::BYTES);
-            vflag = G(kfp->tmpl_valid) + kpi * SVO_LK_LEVELS + level;
+            vflag = tmpl_valid + kpi * SVO_LK_LEVELS + level;
         }
         KLT_PHASE(5);                              // (diagnostic split of phase 1: image views and addresses of the level)
         // A cached level costs memory round trips, not arithmetic (profiles/r03_klt_phases.txt: a third of a
@@ -495,6 +497,7 @@ __device__ __forceinline__ void klt_track_body(const KltArgs* __restrict__ args)
         // compiler from computing its sixteen row addresses before the level loop and holding them through the hot path)
         int lc_b = lc, y0_b = y0;
         asm volatile("" : "+v"(lc_b), "+v"(y0_b));
+        const ImgView I = kfp->lk[level];            // (the keyframe's image: only a template that is built needs it)
         prevx -= halfWin; prevy -= halfWin;
         const int iprevx = cv_floor(prevx), iprevy = cv_floor(prevy);
         if (iprevx < -win || iprevx >= I.w || iprevy < -win || iprevy >= I.h) {
