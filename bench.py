@@ -10,7 +10,8 @@ the reference's EuRoC.yaml settings (4-level SIA pyramid 6/2, 54x48 grid = 130
 cells) — as seeded synthetic sequences (no dataset ships): closed camera loops
 of 192 frames played forward, round and round, so that points leave the image
 and keyframes are created at the reference's rate (every ~25 frames).
-2048 sequences per GPU in 8 sequence groups (weak scaling: the same per rank).
+3584 sequences per GPU in 14 sequence groups of 256 (weak scaling: the same per rank; 2048 in 8
+groups: about 6 % fewer frames/s at half the time per step, profiles/r03_seqs_sweep.txt).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -31,10 +32,10 @@ import sys
 import time
 
 # The ctx drives every sequence group on its own HIP stream; the HIP runtime maps streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise. Eight
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise. Fourteen
 # groups need more: set before anything initialises HIP (a deployment sets it the same way,
 # INTEGRATION.md section 5).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "stereo-svo-slam_amd")):
@@ -284,7 +285,7 @@ def main():
                          "value = median")
     ap.add_argument("--config", default="euroc", choices=sorted(synth.CONFIGS))
     ap.add_argument("--seqs", type=int, default=None,
-                    help="sequences per GPU (default 2048 = eight groups of 256 on eight streams; hd: 512 = eight groups of 64)")
+                    help="sequences per GPU (default 3584 = fourteen groups of 256 on their own streams; hd: 512 = eight groups of 64)")
     ap.add_argument("--loops", type=int, default=None,
                     help="rendered camera loops per GPU (default 128; hd: 16); ctx sequence s plays loop s %% loops, "
                          "sequences that share a loop enter it at different frames")
@@ -320,7 +321,7 @@ def main():
     hd = args.config == "hd"
     K, Wm, reps = args.steps, max(args.warmup, 1), max(args.repeats, 1)
     n_steps = Wm + reps * K
-    B = args.seqs or (512 if hd else 2048)
+    B = args.seqs or (512 if hd else 3584)
     n_loops = min(B, args.loops or (16 if hd else 128))
     nF = args.loop_frames or (48 if hd else LOOP_FRAMES)
     plan = loop_plan(B, n_loops, nF)

@@ -248,7 +248,7 @@ def test_committed_counter_summary_is_reproducible_from_the_csvs(tmp_path, rnd):
                            "reclassify"], stdout=subprocess.DEVNULL)
     new = json.load(open(out / "pmc.json"))
     old = json.load(open(os.path.join(prof, rnd + "_pmc.json")))
-    assert new["seqs"] == old["seqs"] == 2048 and new["groups"] == old["groups"] == 8
+    assert (new["seqs"], new["groups"]) == (old["seqs"], old["groups"]) == ((2048, 8) if rnd == "r02" else (3584, 14))
     if rnd == "r03":      # the chip-level figure bench.py prints: VALU instructions per tracked frame
         assert abs(new["valu_instructions_per_frame"] - old["valu_instructions_per_frame"]) < 1.0
         assert 1.5e6 < new["valu_instructions_per_frame"] < 2.5e6
