@@ -78,7 +78,9 @@ __device__ inline float patch_sum_lds(const LevelImg<BIG>& im, float cx, float c
 #ifndef SVO_SIA_STG
 #define SVO_SIA_STG 64
 #endif
-constexpr int SIA_STG = SVO_SIA_STG;
+// keypoints whose rows are staged at a time in reference-order mode: 64; the one-wave shape can be built with 32
+// (-DSVO_SIA_STG=32: 18 instead of 36 KB of LDS per sequence, two staging rounds per pass)
+__host__ __device__ constexpr int sia_stg(int T) { return T == 64 ? SVO_SIA_STG : 64; }
 #ifndef SVO_SIA_ACC_U
 #define SVO_SIA_ACC_U 4
 #endif
@@ -97,7 +99,7 @@ __host__ __device__ inline SiaLds sia_lds_layout(int img_bytes, int cap, int T, 
     l.rec = off;   off += mode == 2 ? 0 : (size_t)(mode == 1 ? 16 : 64) * cap * 4;
     l.sums = off;  off += (size_t)(T / 64) * 32 * 4 + 32;              // [WAVES][32] + the step wave 0 hands to the others
     // 7 planes of SIA_STG keypoints' rows (20 floats each); several waves per sequence fill two of them in turn
-    l.stage = off; off += exact ? (size_t)(T > 128 ? 2 : 1) * 7 * (SIA_STG * 20 + 4) * 4 : 0;
+    l.stage = off; off += exact ? (size_t)(T > 128 ? 2 : 1) * 7 * (sia_stg(T) * 20 + 4) * 4 : 0;
     l.pipe = off;  off += exact && T > 128 ? 16 : 0;                   // hand-over counters of the two buffers
     l.total = off;
     return l;
@@ -359,6 +361,7 @@ struct Sia {
         float eacc = 0;
         const float wlim = (float)(cur.w - 2), hlim = (float)(cur.h - 2);
         constexpr int KS = 20;                       // floats per keypoint in a staging plane (16 + pad: no write conflicts)
+        constexpr int SIA_STG = sia_stg(T);
         constexpr int PS = SIA_STG * KS + 4;         // plane stride: the 7 planes start on different banks
         float* stage = reinterpret_cast<float*>(dyn + lay.stage);      // [7][PS], index slot*KS + px
 
@@ -487,7 +490,7 @@ struct Sia {
             // (Jacobian, residuals, rows) and fill the two staging buffers ahead of it. Hand-over through LDS
             // counters (a buffer's k-th fill may start when its (k-1)-th has been read). The chain of adds in
             // wave 0 — sequential by definition — is what a gradient call then costs.
-            static_assert(SIA_STG == 64, "the pipelined accumulation hands over whole waves of keypoints");
+            static_assert(WAVES <= 2 || SIA_STG == 64, "the pipelined accumulation hands over whole waves of keypoints");
             SVO_LDS(int)* cnt = (SVO_LDS(int)*)(dyn + lay.pipe);       // [0..1] fills done, [2..3] reads done, per buffer
             float* const stg0 = stage;
             float* const stg1 = stage + 7 * PS;
