@@ -218,6 +218,13 @@ def test_bench_loop_plan_and_group_sample():
             assert (loop, f) not in frames, (k, s, frames.get((loop, f)))
             frames[(loop, f)] = s
     assert [bench.frame_index(k, 192, 190) for k in range(4)] == [190, 191, 0, 1]
+    plan = bench.loop_plan(3584, 128, 192)            # the default: 28 sequences per loop, 6 frames apart
+    assert len(plan) == 3584 and plan[128] == (0, 6) and plan[3583] == (127, 162)
+    for k in (0, 191, 777):
+        shown = {(loop, bench.frame_index(k, 192, off)) for loop, off in plan}
+        assert len(shown) == 3584
+    seqs, groups = bench.group_sample(3584, 14)
+    assert seqs[:14] == [256 * g for g in range(14)] and len(set(groups[:16])) == 14
     seqs, groups = bench.group_sample(2048, 8)
     assert seqs[:8] == [0, 256, 512, 768, 1024, 1280, 1536, 1792] and groups[:8] == list(range(8))
     assert seqs[8:] == [s + 1 for s in seqs[:8]] and len(set(groups)) == 8
