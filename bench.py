@@ -397,6 +397,19 @@ def main():
                                 "note": "the streaming stage: algorithmic bytes B_P of DESIGN.md section 5 / event time of "
                                         "the stage (measured beside the other groups' kernels)"}
     roofline["pyramids_hbm"]["frac"] = roofline["pyramids_hbm"]["achieved"] / HBM_PEAK_GBS
+    # the same kernel ALONE on the GPU (one group of 256 sequences): replayed from the committed kernel statistics
+    alone_csv = os.path.join(ROOT, "profiles", "r03_kernel_stats_1group_256seq.csv")
+    if args.config == "euroc" and os.path.exists(alone_csv):
+        import csv
+        for row in csv.DictReader(open(alone_csv)):
+            if "pyr_stream_kernel" in row["Name"]:
+                alone_s = float(row["AverageNs"]) * 1e-9
+                roofline["pyramids_hbm"]["alone"] = {
+                    "achieved": ab["images+pyramids"] * 256 / alone_s / 1e9, "frac": ab["images+pyramids"] * 256 / alone_s / 1e9 / HBM_PEAK_GBS,
+                    "avg_launch_ms": alone_s * 1e3,
+                    "source": "profiles/r03_kernel_stats_1group_256seq.csv (rocprofv3 --kernel-trace --stats of an earlier run with "
+                              "SVO_GROUPS=1 --seqs 256, replayed; not measured in this run)"}
+                break
     win_d, sx_, sy_ = cfg["window_size_depth_calculator"], cfg["search_x"], cfg["search_y"]
     mfma_per_kp = win_d * ((sx_ + 1 + 15) // 16) * ((2 * sy_ + 1 + 15) // 16)
     ops = 2.0 * 16 * 16 * 64 * mfma_per_kp * mean_kps * seqs_per_launch
@@ -517,6 +530,7 @@ def main():
         "parity_groups_covered": cpu and cpu["parity"] and cpu["parity"]["groups_covered"],
         "valu_issue_frac_of_step": valu and valu["frac"],
         "issue_active_frac_of_step": issue and issue["per_simd_cycle"],
+        "pyramids_hbm_frac_alone_replayed": roofline["pyramids_hbm"].get("alone", {}).get("frac"),
         "c3_fps": c3 and c3["frames_per_s"], "c3_pyramids_hbm_frac": c3 and c3["pyramids_hbm_frac"],
         "setup_s": t_setup, "wall_s": time.perf_counter() - t_start,
         "config": {"workload": f"{args.config}: {WORKLOAD_LABEL.get(args.config, 'synthetic')} {cfg['width']}x{cfg['height']} stereo, "
